@@ -1,0 +1,23 @@
+# Builds the product library (HIP kernels + C ABI + host mirror) for gfx950
+# and the CPU oracle.  `make` here == __graft_entry__.build().
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+# -ffp-contract=off: results are compared bit-for-bit with an unfused f64 reference.
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -munsafe-fp-atomics -Wall -Wno-unused-result
+
+LIB  := raytracing_amd/librtx.so
+SRCS := raytracing_amd/csrc/rtx_kernels.hip raytracing_amd/csrc/rtx_api.cpp raytracing_amd/host/rtx_host.cpp
+HDRS := include/rtx.h include/rtx_host.h raytracing_amd/csrc/rtx_device.h raytracing_amd/csrc/rtx_kernels.h raytracing_amd/host/raytracing.hpp
+
+all: $(LIB) oracle
+
+$(LIB): $(SRCS) $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ -x hip $(SRCS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(LIB)
+	$(MAKE) -C oracle clean
+.PHONY: all oracle clean

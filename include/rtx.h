@@ -1,0 +1,180 @@
+/*
+ * rtx.h -- C ABI of the MI355X render backend.
+ *
+ * This is the drop-in boundary for the per-pixel sample/bounce loop of
+ * seridescent/raytracing.  The reference has no FFI; the path sits behind
+ *     trait Hittable::hit              (src/surface.rs:9-12)
+ *     InitializedCamera::render        (src/camera.rs:128-162)
+ *     RenderRunner::run                (src/runner.rs:23-41)
+ * A per-ray Hittable call is the wrong granularity for a GPU, so the ABI
+ * replaces the two batch operations those calls add up to:
+ *     trace_closest(rays)  -> (surface id, t)      == BVH::hit over a batch
+ *     render(camera, bvh)  -> linear RGB image     == the sample loop
+ * All types are POD, all pointers are plain, all functions return an int
+ * status (0 = OK, < 0 = error, message via rtx_last_error()).  Nothing
+ * throws or aborts across this boundary.  Citations are into the reference.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_NONE 0xFFFFFFFFu
+
+enum rtx_status {
+    RTX_OK = 0,
+    RTX_ERR_BAD_ARG = -1,
+    RTX_ERR_NO_DEVICE = -2,
+    RTX_ERR_HIP = -3,
+    RTX_ERR_OOM = -4,
+    RTX_ERR_BUILD = -5
+};
+
+/* enum Geometry, src/geometry.rs:25-47 */
+enum rtx_geom_kind { RTX_SPHERE = 0, RTX_QUAD = 1, RTX_TRIANGLE = 2 };
+/* enum Material, src/material.rs:9-17 */
+enum rtx_mat_kind { RTX_LAMBERTIAN = 0, RTX_METAL = 1, RTX_DIELECTRIC = 2, RTX_DIFFUSE_LIGHT = 3, RTX_UV_GRADIENT = 4 };
+
+/*
+ * A built BVH, flattened.  Replaces `BVH { tree: Box<[Node]> }`
+ * (src/bvh/mod.rs:51-73): the same pre-order array (left child of node i is
+ * i+1) with each enum field moved into its own table.  Vector tables are
+ * stored as three rows: x[0..n), y[0..n), z[0..n).
+ *
+ * Boxes must be the ones the reference computes (Node::bounding_box,
+ * src/bvh/mod.rs:59-69), including the leaf boxes: the box test is part of
+ * the observable result, not only an optimisation.
+ */
+typedef struct rtx_scene_desc {
+    uint32_t n_nodes;
+    uint32_t n_prims;
+    uint32_t n_materials;
+    uint32_t _reserved;
+
+    const double*   node_bmin;      /* [3][n_nodes] */
+    const double*   node_bmax;      /* [3][n_nodes] */
+    const uint32_t* node_right;     /* Internal: right_idx; Leaf: RTX_NONE */
+    const uint32_t* node_prim;      /* Leaf: index into the prim tables; Internal: RTX_NONE */
+
+    const uint8_t*  prim_kind;      /* rtx_geom_kind */
+    const double*   prim_q;         /* [3][n_prims]  sphere: center; planar: q */
+    const double*   prim_u;         /* [3][n_prims]  planar only (src/geometry.rs:31-46) */
+    const double*   prim_v;
+    const double*   prim_norm;
+    const double*   prim_w;
+    const double*   prim_d;         /* [n_prims]     planar only */
+    const double*   prim_radius;    /* [n_prims]     sphere only */
+    const uint32_t* prim_material;  /* index into the material tables */
+    const uint32_t* prim_user_id;   /* index of the surface in the caller's original array */
+
+    const uint32_t* mat_kind;       /* rtx_mat_kind */
+    const double*   mat_rgb;        /* [3][n_materials] albedo | emit */
+    const double*   mat_param;      /* fuzz_radius | refraction_index | intensity */
+} rtx_scene_desc;
+
+/* The fields of InitializedCamera, src/camera.rs:28-43 (all private there). */
+typedef struct rtx_camera {
+    uint32_t image_width;
+    uint32_t image_height;
+    uint32_t samples_per_pixel;
+    uint32_t max_depth;
+    double defocus_angle;
+    double background[3];
+    double pixel_samples_scale;
+    double center[3];
+    double pixel00_loc[3];
+    double pixel_du[3];
+    double pixel_dv[3];
+    double defocus_disk_u[3];
+    double defocus_disk_v[3];
+} rtx_camera;
+
+/* Counters and timers of one call (the reference has only the three
+ * wall-clock timers of src/runner.rs:24-38 and no ray counter). */
+typedef struct rtx_stats {
+    uint64_t rays;           /* closest-hit queries == world.hit() calls, every bounce */
+    uint64_t paths;          /* primary samples */
+    uint64_t node_visits;    /* box tests (0 unless counting was requested) */
+    uint64_t sphere_tests;
+    uint64_t planar_tests;
+    uint64_t iterations;     /* traverse+shade rounds launched */
+    double   ms_total;       /* device time of the call, HIP events */
+    double   ms_traverse;    /* summed duration of the traverse kernel launches (0 unless RTX_FLAG_TIME_KERNELS) */
+    double   ms_shade;
+} rtx_stats;
+
+typedef struct rtx_scene rtx_scene;
+
+/* flags for rtx_render_accumulate / rtx_trace_closest */
+#define RTX_FLAG_COUNT_WORK   1u  /* fill node_visits / *_tests (slower) */
+#define RTX_FLAG_TIME_KERNELS 2u  /* time every traverse / shade launch with HIP events */
+#define RTX_FLAG_EXACT_DIVIDE 4u  /* box test by six true divisions per node instead of the filtered form */
+
+/* Message of the calling thread's last failed call. */
+const char* rtx_last_error(void);
+
+/* Number of visible HIP devices (0 when there is none). */
+int rtx_device_count(void);
+
+/* Copies the flattened BVH into HBM of the current HIP device.  Replaces
+ * holding `world: BVH` across the render (src/runner.rs:27-31).  The caller
+ * keeps ownership of every array in `desc`; they are not referenced after
+ * the call returns. */
+int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out);
+void rtx_scene_destroy(rtx_scene* scene);
+
+/* Closest hit for n rays.  Replaces n calls of `impl Hittable for BVH::hit`
+ * (src/bvh/mod.rs:134-174) with ray_t = [tmin, tmax].  org/dir: host, [n][3].
+ * out_id[i] = prim_user_id of the hit surface or RTX_NONE; out_t[i] = hit.t
+ * (+inf on a miss).  stats may be NULL. */
+int rtx_trace_closest(rtx_scene* scene, const double* org, const double* dir, uint64_t n,
+                      double tmin, double tmax, uint32_t flags,
+                      uint32_t* out_id, double* out_t, rtx_stats* stats);
+
+/* Primary rays of sample index `sample` for every pixel, as the render
+ * kernels generate them (sample_square + get_ray, src/camera.rs:164-182).
+ * org/dir: host, [W*H][3]. */
+int rtx_primary_rays(const rtx_camera* cam, uint64_t seed, uint32_t sample, double* org, double* dir);
+
+/* The sample loop of InitializedCamera::render (src/camera.rs:133-151) for
+ * sample indices [spp_begin, spp_begin+spp_count) of every pixel.  ADDS the
+ * unscaled radiance sums into d_accum (device memory of the scene's device,
+ * [H][W][3] f64, pixel = row*W+col as src/camera.rs:139).  Work is enqueued
+ * on `stream` (a hipStream_t, NULL = default stream); the call returns after
+ * the work has completed.  Sample s of pixel p always uses RNG stream
+ * (seed, p, s), so any split of the sample range over calls or GPUs yields
+ * the same image up to the order of floating-point addition. */
+int rtx_render_accumulate(rtx_scene* scene, const rtx_camera* cam, uint64_t seed,
+                          uint32_t spp_begin, uint32_t spp_count, uint32_t flags,
+                          double* d_accum, void* stream, rtx_stats* stats);
+
+/* out[i] = accum[i] * scale on the device (`* self.pixel_samples_scale`,
+ * src/camera.rs:146).  May run in place. */
+int rtx_scale(const double* d_accum, uint64_t n_values, double scale, double* d_out, void* stream);
+
+/* ppm_pixel (src/camera.rs:248-266) on the device: gamma, clamp, 8-bit. */
+int rtx_quantize(const double* d_rgb, uint64_t n_values, uint8_t* d_out, void* stream);
+
+/* Whole render on the current device with host output: out_rgb is host
+ * memory, [H][W][3] f64 linear RGB already multiplied by 1/spp.  Replaces
+ * `camera.initialize().render(&world)` (src/runner.rs:31) minus the PPM
+ * text output. */
+int rtx_render(rtx_scene* scene, const rtx_camera* cam, uint64_t seed, uint32_t flags,
+               double* out_rgb, rtx_stats* stats);
+
+/* Device arithmetic self-test hooks used by the parity tests:
+ * op 0: out[i] = a[i] / b[i]; op 1: out[i] = sqrt(a[i]);
+ * op 2: out[i] = filtered-quotient of a[i], b[i] as the box test computes it. */
+int rtx_selftest_math(int op, const double* a, const double* b, uint64_t n, double* out);
+
+/* Philox4x32-10 uniform doubles of stream (seed, pixel, sample) computed on the device. */
+int rtx_selftest_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

@@ -1,0 +1,494 @@
+// rtx_api.cpp -- the C ABI declared in include/rtx.h, on top of the kernels.
+//
+// Host-side responsibilities: validate and upload the flattened BVH, own the
+// path pool, drive the traverse/shade rounds, and report counters and times.
+#include "../../include/rtx.h"
+#include "rtx_kernels.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rtx;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) {                                                                            \
+            int code = (_e == hipErrorOutOfMemory) ? RTX_ERR_OOM : (_e == hipErrorNoDevice ? RTX_ERR_NO_DEVICE : RTX_ERR_HIP); \
+            return fail(code, std::string(#expr) + ": " + hipGetErrorString(_e));                         \
+        }                                                                                                  \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t resize(size_t count) {
+        if (count <= n) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc((void**)&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    char* end = nullptr;
+    unsigned long long x = std::strtoull(v, &end, 10);
+    if (end == v || x == 0 || x > 0xFFFFFFFFull) return dflt;
+    return (uint32_t)x;
+}
+
+}  // namespace
+
+struct rtx_scene {
+    int device = 0;
+    uint32_t n_cus = 256;
+    DScene d{};
+    DevBuf<DNode> nodes;
+    DevBuf<DSphere> spheres;
+    DevBuf<DPlanar> planars;
+    DevBuf<DPrimInfo> prims;
+    DevBuf<DMaterial> materials;
+    // path pool, sized on first use and kept
+    size_t pool_slots = 0;
+    DevBuf<double> pool_f64;     // 10 arrays
+    DevBuf<uint32_t> pool_u32;   // 5 arrays + 2 queues
+    DevBuf<DRenderCtl> ctl;
+    DPool pool{};
+    uint32_t* queue[2] = {nullptr, nullptr};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    int ensure_pool(size_t slots) {
+        if (slots <= pool_slots) return RTX_OK;
+        HIP_TRY(pool_f64.resize(10 * slots));
+        HIP_TRY(pool_u32.resize(7 * slots));
+        HIP_TRY(ctl.resize(1));
+        double* f = pool_f64.p;
+        pool.ox = f + 0 * slots; pool.oy = f + 1 * slots; pool.oz = f + 2 * slots;
+        pool.dx = f + 3 * slots; pool.dy = f + 4 * slots; pool.dz = f + 5 * slots;
+        pool.bx = f + 6 * slots; pool.by = f + 7 * slots; pool.bz = f + 8 * slots;
+        pool.hit_t = f + 9 * slots;
+        uint32_t* u = pool_u32.p;
+        pool.pixel = u + 0 * slots; pool.sample = u + 1 * slots; pool.draw = u + 2 * slots; pool.depth = u + 3 * slots;
+        pool.hit_prim = u + 4 * slots;
+        queue[0] = u + 5 * slots;
+        queue[1] = u + 6 * slots;
+        pool_slots = slots;
+        return RTX_OK;
+    }
+};
+
+extern "C" {
+
+const char* rtx_last_error(void) { return g_err.c_str(); }
+
+int rtx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
+    if (!desc || !out) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: null argument");
+    *out = nullptr;
+    const uint32_t n = desc->n_nodes, m = desc->n_prims, k = desc->n_materials;
+    if (n && (!desc->node_bmin || !desc->node_bmax || !desc->node_right || !desc->node_prim))
+        return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: null node table");
+    if (m && (!desc->prim_kind || !desc->prim_q || !desc->prim_material || !desc->prim_user_id))
+        return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: null prim table");
+    if (k && (!desc->mat_kind || !desc->mat_rgb || !desc->mat_param))
+        return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: null material table");
+
+    // prims -> per-kind tables
+    std::vector<DSphere> spheres;
+    std::vector<DPlanar> planars;
+    std::vector<DPrimInfo> prims(m);
+    for (uint32_t i = 0; i < m; ++i) {
+        uint32_t kind = desc->prim_kind[i];
+        if (kind > RTX_TRIANGLE) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: unknown geometry kind");
+        if (desc->prim_material[i] >= k) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: prim_material out of range");
+        prims[i].kind = kind;
+        prims[i].material = desc->prim_material[i];
+        prims[i].user_id = desc->prim_user_id[i];
+        if (kind == RTX_SPHERE) {
+            if (!desc->prim_radius) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: null prim_radius");
+            DSphere s;
+            for (int a = 0; a < 3; ++a) s.c[a] = desc->prim_q[(size_t)a * m + i];
+            s.r = desc->prim_radius[i];
+            prims[i].slot = (uint32_t)spheres.size();
+            spheres.push_back(s);
+        } else {
+            if (!desc->prim_u || !desc->prim_v || !desc->prim_norm || !desc->prim_w || !desc->prim_d)
+                return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: null planar table");
+            DPlanar g;
+            for (int a = 0; a < 3; ++a) {
+                g.q[a] = desc->prim_q[(size_t)a * m + i];
+                g.u[a] = desc->prim_u[(size_t)a * m + i];
+                g.v[a] = desc->prim_v[(size_t)a * m + i];
+                g.norm[a] = desc->prim_norm[(size_t)a * m + i];
+                g.w[a] = desc->prim_w[(size_t)a * m + i];
+            }
+            g.d = desc->prim_d[i];
+            prims[i].slot = (uint32_t)planars.size();
+            planars.push_back(g);
+        }
+    }
+    std::vector<DMaterial> mats(k);
+    for (uint32_t i = 0; i < k; ++i) {
+        if (desc->mat_kind[i] > RTX_UV_GRADIENT) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: unknown material kind");
+        for (int a = 0; a < 3; ++a) mats[i].rgb[a] = desc->mat_rgb[(size_t)a * k + i];
+        mats[i].param = desc->mat_param[i];
+        mats[i].kind = desc->mat_kind[i];
+        mats[i]._pad = 0;
+    }
+
+    // nodes: thread the pre-order array.  A parent precedes its children, so
+    // one forward pass fills every successor: the left child (i+1) is
+    // followed by the right child, the right child by the parent's successor.
+    std::vector<DNode> nodes(n);
+    std::vector<uint32_t> miss(n, NONE);
+    bool filter_ok = true;
+    if (n) miss[0] = n;
+    for (uint32_t i = 0; i < n; ++i) {
+        DNode& nd = nodes[i];
+        for (int a = 0; a < 3; ++a) {
+            nd.bmin[a] = desc->node_bmin[(size_t)a * n + i];
+            nd.bmax[a] = desc->node_bmax[(size_t)a * n + i];
+            if (!(std::fabs(nd.bmin[a]) <= 0x1.0p300) || !(std::fabs(nd.bmax[a]) <= 0x1.0p300)) filter_ok = false;
+        }
+        if (miss[i] == NONE) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: node " + std::to_string(i) + " is not reachable in pre-order");
+        if (miss[i] <= i || miss[i] > n) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: malformed tree");
+        nd.miss = miss[i];
+        uint32_t prim = desc->node_prim[i];
+        uint32_t right = desc->node_right[i];
+        if (prim != RTX_NONE) {   // Node::Leaf
+            if (prim >= m) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: node_prim out of range");
+            if (right != RTX_NONE) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: leaf with a right child");
+            if (miss[i] != i + 1) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: leaf subtree is not a single node");
+            nd.prim = prim;
+            nd.kind = prims[prim].kind;
+            nd.slot = prims[prim].slot;
+        } else {                  // Node::Internal(Some(right_idx), box)
+            if (right == RTX_NONE || right <= i + 1 || right >= miss[i])
+                return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: right child index out of order at node " + std::to_string(i));
+            nd.prim = NONE;
+            nd.kind = 0;
+            nd.slot = 0;
+            miss[i + 1] = right;
+            miss[right] = miss[i];
+        }
+    }
+
+    rtx_scene* sc = new rtx_scene();
+    auto bail = [&](int code) {
+        delete sc;
+        return code;
+    };
+    hipError_t e = hipGetDevice(&sc->device);
+    if (e != hipSuccess) return bail(fail(RTX_ERR_NO_DEVICE, std::string("hipGetDevice: ") + hipGetErrorString(e)));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess && prop.multiProcessorCount > 0) sc->n_cus = (uint32_t)prop.multiProcessorCount;
+
+#define UP(buf, vec)                                                                                                   \
+    do {                                                                                                               \
+        hipError_t _e = sc->buf.resize((vec).size());                                                                  \
+        if (_e == hipSuccess && !(vec).empty()) _e = hipMemcpy(sc->buf.p, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice); \
+        if (_e != hipSuccess) return bail(fail(_e == hipErrorOutOfMemory ? RTX_ERR_OOM : RTX_ERR_HIP, std::string("scene upload: ") + hipGetErrorString(_e))); \
+    } while (0)
+    UP(nodes, nodes);
+    UP(spheres, spheres);
+    UP(planars, planars);
+    UP(prims, prims);
+    UP(materials, mats);
+#undef UP
+    sc->d.nodes = sc->nodes.p;
+    sc->d.spheres = sc->spheres.p;
+    sc->d.planars = sc->planars.p;
+    sc->d.prims = sc->prims.p;
+    sc->d.materials = sc->materials.p;
+    sc->d.n_nodes = n;
+    sc->d.n_prims = m;
+    sc->d.filter_ok = filter_ok ? 1u : 0u;
+    if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
+        return bail(fail(RTX_ERR_HIP, "hipEventCreate failed"));
+    *out = sc;
+    return RTX_OK;
+}
+
+void rtx_scene_destroy(rtx_scene* sc) {
+    if (!sc) return;
+    if (sc->ev0) (void)hipEventDestroy(sc->ev0);
+    if (sc->ev1) (void)hipEventDestroy(sc->ev1);
+    delete sc;
+}
+
+static int read_counters(rtx_scene* sc, hipStream_t s, rtx_stats* stats) {
+    DRenderCtl h;
+    HIP_TRY(hipMemcpyAsync(&h, sc->ctl.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    stats->rays += h.rays;
+    stats->node_visits += h.node_visits;
+    stats->sphere_tests += h.sphere_tests;
+    stats->planar_tests += h.planar_tests;
+    return RTX_OK;
+}
+
+int rtx_trace_closest(rtx_scene* sc, const double* org, const double* dir, uint64_t n, double tmin, double tmax,
+                      uint32_t flags, uint32_t* out_id, double* out_t, rtx_stats* stats) {
+    if (!sc || (n && (!org || !dir || !out_id || !out_t))) return fail(RTX_ERR_BAD_ARG, "rtx_trace_closest: null argument");
+    if (n > 0xFFFFFFFFull) return fail(RTX_ERR_BAD_ARG, "rtx_trace_closest: more than 2^32-1 rays in one call");
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (n == 0) return RTX_OK;
+    HIP_TRY(hipSetDevice(sc->device));
+    int rc = sc->ensure_pool((size_t)n);
+    if (rc != RTX_OK) return rc;
+    hipStream_t s = nullptr;
+    DevBuf<double> d_rays;
+    HIP_TRY(d_rays.resize(6 * n));
+    HIP_TRY(hipMemcpyAsync(d_rays.p, org, 3 * n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_rays.p + 3 * n, dir, 3 * n * sizeof(double), hipMemcpyHostToDevice, s));
+    DRenderCtl h{};
+    h.count[0] = (uint32_t)n;
+    HIP_TRY(hipMemcpyAsync(sc->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    launch_rays_to_pool(d_rays.p, d_rays.p + 3 * n, n, sc->pool, s);
+    const uint32_t max_blocks = sc->n_cus * 8;
+    HIP_TRY(hipEventRecord(sc->ev0, s));
+    launch_traverse(sc->d, sc->pool, nullptr, &sc->ctl.p->count[0], nullptr, n, tmin, tmax, sc->ctl.p,
+                    (flags & RTX_FLAG_COUNT_WORK) != 0, (flags & RTX_FLAG_EXACT_DIVIDE) != 0, max_blocks, s);
+    HIP_TRY(hipEventRecord(sc->ev1, s));
+    launch_user_ids(sc->d.prims, sc->pool.hit_prim, n, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_id, sc->pool.hit_prim, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_t, sc->pool.hit_t, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (uint64_t i = 0; i < n; ++i)
+        if (out_id[i] == RTX_NONE) out_t[i] = INFINITY;
+    if (stats) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
+        stats->ms_total = ms;
+        stats->ms_traverse = ms;
+        stats->iterations = 1;
+        rc = read_counters(sc, s, stats);
+        if (rc != RTX_OK) return rc;
+    }
+    return RTX_OK;
+}
+
+static DCamera to_dcamera(const rtx_camera* c) {
+    DCamera d{};
+    d.image_width = c->image_width;
+    d.image_height = c->image_height;
+    d.samples_per_pixel = c->samples_per_pixel;
+    d.max_depth = c->max_depth;
+    d.defocus_angle = c->defocus_angle;
+    for (int a = 0; a < 3; ++a) {
+        d.background[a] = c->background[a];
+        d.center[a] = c->center[a];
+        d.pixel00_loc[a] = c->pixel00_loc[a];
+        d.pixel_du[a] = c->pixel_du[a];
+        d.pixel_dv[a] = c->pixel_dv[a];
+        d.defocus_disk_u[a] = c->defocus_disk_u[a];
+        d.defocus_disk_v[a] = c->defocus_disk_v[a];
+    }
+    return d;
+}
+
+static int check_camera(const rtx_camera* cam, const char* who) {
+    if (!cam) return fail(RTX_ERR_BAD_ARG, std::string(who) + ": null camera");
+    if (cam->image_width == 0 || cam->image_height == 0) return fail(RTX_ERR_BAD_ARG, std::string(who) + ": empty image");
+    if ((uint64_t)cam->image_width * cam->image_height > 0xFFFFFFFFull)
+        return fail(RTX_ERR_BAD_ARG, std::string(who) + ": more than 2^32-1 pixels");
+    return RTX_OK;
+}
+
+int rtx_primary_rays(const rtx_camera* cam, uint64_t seed, uint32_t sample, double* org, double* dir) {
+    int rc = check_camera(cam, "rtx_primary_rays");
+    if (rc != RTX_OK) return rc;
+    if (!org || !dir) return fail(RTX_ERR_BAD_ARG, "rtx_primary_rays: null output");
+    const uint32_t npix = cam->image_width * cam->image_height;
+    DevBuf<double> d;
+    HIP_TRY(d.resize(6 * (size_t)npix));
+    launch_primary_rays(to_dcamera(cam), seed, sample, npix, d.p, d.p + 3 * (size_t)npix, 2048, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(org, d.p, 3 * (size_t)npix * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dir, d.p + 3 * (size_t)npix, 3 * (size_t)npix * sizeof(double), hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, uint32_t spp_begin, uint32_t spp_count,
+                          uint32_t flags, double* d_accum, void* stream, rtx_stats* stats) {
+    if (!sc || !d_accum) return fail(RTX_ERR_BAD_ARG, "rtx_render_accumulate: null argument");
+    int rc = check_camera(cam, "rtx_render_accumulate");
+    if (rc != RTX_OK) return rc;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    const uint64_t npix = (uint64_t)cam->image_width * cam->image_height;
+    const uint64_t total = npix * spp_count;
+    if (total == 0 || cam->max_depth == 0) return RTX_OK;   // ray_color returns ZERO at remaining == 0 (camera.rs:190-192)
+    if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(RTX_ERR_BAD_ARG, "rtx_render_accumulate: sample index overflow");
+    HIP_TRY(hipSetDevice(sc->device));
+    hipStream_t s = (hipStream_t)stream;
+
+    const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 22);
+    const uint32_t slots = (uint32_t)(total < want ? total : want);
+    rc = sc->ensure_pool(slots);
+    if (rc != RTX_OK) return rc;
+    const uint32_t max_blocks = sc->n_cus * env_u32("RTX_BLOCKS_PER_CU", 8);
+    const uint32_t check_every = env_u32("RTX_CHECK_EVERY", 4);
+    const bool count_work = (flags & RTX_FLAG_COUNT_WORK) != 0;
+    const bool exact = (flags & RTX_FLAG_EXACT_DIVIDE) != 0;
+    const bool time_kernels = (flags & RTX_FLAG_TIME_KERNELS) != 0;
+    const DCamera dcam = to_dcamera(cam);
+
+    DRenderCtl h{};
+    h.next_path = slots;
+    h.total_paths = total;
+    h.count[0] = slots;
+    HIP_TRY(hipMemcpyAsync(sc->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(sc->ev0, s));
+    launch_generate(dcam, sc->pool, slots, seed, spp_begin, sc->queue[0], max_blocks, s);
+
+    std::vector<hipEvent_t> evs;   // only with RTX_FLAG_TIME_KERNELS: 3 per round
+    uint32_t* h_count = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&h_count, sizeof(uint32_t), hipHostMallocDefault));
+    *h_count = slots;
+    uint64_t iters = 0;
+    int cur = 0;
+    int status = RTX_OK;
+    for (;;) {
+        const int nxt = cur ^ 1;
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+        if (time_kernels) {
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) {
+                status = fail(RTX_ERR_HIP, "hipEventCreate failed");
+                break;
+            }
+            evs.push_back(e0); evs.push_back(e1); evs.push_back(e2);
+            (void)hipEventRecord(e0, s);
+        }
+        launch_traverse(sc->d, sc->pool, sc->queue[cur], &sc->ctl.p->count[cur], &sc->ctl.p->count[nxt], slots, 0.001,
+                        INFINITY, sc->ctl.p, count_work, exact, max_blocks, s);   // Interval(0.001, inf), camera.rs:194
+        if (time_kernels) (void)hipEventRecord(e1, s);
+        launch_shade(sc->d, dcam, sc->pool, sc->queue[cur], &sc->ctl.p->count[cur], sc->queue[nxt], &sc->ctl.p->count[nxt],
+                     slots, sc->ctl.p, seed, spp_begin, d_accum, max_blocks, s);
+        if (time_kernels) (void)hipEventRecord(e2, s);
+        ++iters;
+        cur = nxt;
+        if (iters % check_every == 0) {
+            hipError_t e = hipMemcpyAsync(h_count, &sc->ctl.p->count[cur], sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) {
+                status = fail(RTX_ERR_HIP, std::string("render loop: ") + hipGetErrorString(e));
+                break;
+            }
+            if (*h_count == 0) break;
+        }
+    }
+    (void)hipHostFree(h_count);
+    if (status == RTX_OK) {
+        hipError_t e = hipEventRecord(sc->ev1, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) status = fail(RTX_ERR_HIP, std::string("render: ") + hipGetErrorString(e));
+    }
+    if (status == RTX_OK && stats) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, sc->ev0, sc->ev1);
+        stats->ms_total = ms;
+        stats->paths = total;
+        stats->iterations = iters;
+        for (size_t i = 0; i + 2 < evs.size(); i += 3) {
+            float a = 0.f, b = 0.f;
+            (void)hipEventElapsedTime(&a, evs[i], evs[i + 1]);
+            (void)hipEventElapsedTime(&b, evs[i + 1], evs[i + 2]);
+            stats->ms_traverse += a;
+            stats->ms_shade += b;
+        }
+        status = read_counters(sc, s, stats);
+    }
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    return status;
+}
+
+int rtx_scale(const double* d_accum, uint64_t n, double scale, double* d_out, void* stream) {
+    if (n && (!d_accum || !d_out)) return fail(RTX_ERR_BAD_ARG, "rtx_scale: null argument");
+    if (n == 0) return RTX_OK;
+    launch_scale(d_accum, n, scale, d_out, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return RTX_OK;
+}
+
+int rtx_quantize(const double* d_rgb, uint64_t n, uint8_t* d_out, void* stream) {
+    if (n && (!d_rgb || !d_out)) return fail(RTX_ERR_BAD_ARG, "rtx_quantize: null argument");
+    if (n == 0) return RTX_OK;
+    launch_quantize(d_rgb, n, d_out, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return RTX_OK;
+}
+
+int rtx_render(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, uint32_t flags, double* out_rgb, rtx_stats* stats) {
+    if (!sc || !out_rgb) return fail(RTX_ERR_BAD_ARG, "rtx_render: null argument");
+    int rc = check_camera(cam, "rtx_render");
+    if (rc != RTX_OK) return rc;
+    HIP_TRY(hipSetDevice(sc->device));
+    const uint64_t nval = 3ull * cam->image_width * cam->image_height;
+    DevBuf<double> acc;
+    HIP_TRY(acc.resize(nval));
+    HIP_TRY(hipMemset(acc.p, 0, nval * sizeof(double)));
+    rc = rtx_render_accumulate(sc, cam, seed, 0, cam->samples_per_pixel, flags, acc.p, nullptr, stats);
+    if (rc != RTX_OK) return rc;
+    rc = rtx_scale(acc.p, nval, cam->pixel_samples_scale, acc.p, nullptr);
+    if (rc != RTX_OK) return rc;
+    HIP_TRY(hipMemcpy(out_rgb, acc.p, nval * sizeof(double), hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_selftest_math(int op, const double* a, const double* b, uint64_t n, double* out) {
+    if (n && (!a || !b || !out)) return fail(RTX_ERR_BAD_ARG, "rtx_selftest_math: null argument");
+    if (n == 0) return RTX_OK;
+    DevBuf<double> d;
+    HIP_TRY(d.resize(3 * n));
+    HIP_TRY(hipMemcpy(d.p, a, n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.p + n, b, n * sizeof(double), hipMemcpyHostToDevice));
+    launch_selftest_math(op, d.p, d.p + n, n, d.p + 2 * n, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d.p + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_selftest_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, double* out) {
+    if (n && !out) return fail(RTX_ERR_BAD_ARG, "rtx_selftest_rng: null argument");
+    if (n == 0) return RTX_OK;
+    DevBuf<double> d;
+    HIP_TRY(d.resize(n));
+    launch_selftest_rng(seed, pixel, sample, n, d.p, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// rtx_device.h -- device-side data layout and arithmetic of the render path.
+//
+// Everything here is f64 and must be compiled with -ffp-contract=off: the
+// reference (Rust) never fuses a*b+c, and closest-hit ids are compared
+// bit-for-bit against a CPU restatement of it.  Citations "file:line" are
+// into the reference repository seridescent/raytracing.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtx {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+// ---------------------------------------------------------------- layout in HBM
+// One BVH node = one 64-byte record, so a lane's node fetch touches exactly
+// one cache line whatever node it is on.  `miss` threads the pre-order array:
+// it is the next node in pre-order outside this node's subtree, i.e. exactly
+// the node the reference's explicit stack (src/bvh/mod.rs:135-156) would pop
+// next after this subtree is finished or culled.
+struct __attribute__((aligned(64))) DNode {
+    double bmin[3];
+    double bmax[3];
+    uint32_t miss;   // next node when the box is missed or the leaf is done
+    uint32_t prim;   // leaf: prim index; internal: NONE
+    uint32_t kind;   // leaf: geometry kind
+    uint32_t slot;   // leaf: index into the sphere / planar table
+};
+static_assert(sizeof(DNode) == 64, "node record must be one 64-byte line");
+
+struct __attribute__((aligned(32))) DSphere {   // Geometry::Sphere, src/geometry.rs:27-30
+    double c[3];
+    double r;
+};
+struct __attribute__((aligned(128))) DPlanar {  // Geometry::Quadrilateral / Triangle, src/geometry.rs:31-46
+    double q[3], u[3], v[3], norm[3], w[3];
+    double d;
+};
+struct DPrimInfo {
+    uint32_t kind, slot, material, user_id;
+};
+struct DMaterial {                              // enum Material, src/material.rs:9-17
+    double rgb[3];
+    double param;
+    uint32_t kind;
+    uint32_t _pad;
+};
+
+struct DScene {
+    const DNode* nodes;
+    const DSphere* spheres;
+    const DPlanar* planars;
+    const DPrimInfo* prims;
+    const DMaterial* materials;
+    uint32_t n_nodes;
+    uint32_t n_prims;
+    uint32_t filter_ok;   // every box coordinate is finite and small enough for the filtered box test
+};
+
+// Path pool: one slot per path in flight, struct-of-arrays so that a wave's
+// loads and stores of one field are contiguous.
+struct DPool {
+    double *ox, *oy, *oz, *dx, *dy, *dz;   // current ray (src/ray.rs:4-7)
+    double *bx, *by, *bz;                  // product of attenuations so far
+    uint32_t *pixel, *sample, *draw, *depth;
+    uint32_t* hit_prim;                    // closest-hit record of the current ray
+    double* hit_t;
+};
+
+struct DCamera {   // InitializedCamera, src/camera.rs:28-43
+    uint32_t image_width, image_height, samples_per_pixel, max_depth;
+    double defocus_angle;
+    double background[3];
+    double center[3], pixel00_loc[3], pixel_du[3], pixel_dv[3], defocus_disk_u[3], defocus_disk_v[3];
+};
+
+// Control block of one render call (device memory).
+struct DRenderCtl {
+    unsigned long long next_path;    // next unstarted (pixel, sample) index
+    unsigned long long total_paths;
+    unsigned long long rays;         // closest-hit queries issued so far
+    unsigned long long node_visits, sphere_tests, planar_tests;
+    uint32_t count[2];               // live entries of the two slot queues
+};
+
+// ---------------------------------------------------------------- Vector3 (src/vector.rs)
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return a * s; }
+__device__ __forceinline__ V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+// Vector3 / f64 multiplies by the reciprocal (src/vector.rs:179-190)
+__device__ __forceinline__ V3 operator/(V3 a, double s) {
+    double inv = 1.0 / s;
+    return v3(a.x * inv, a.y * inv, a.z * inv);
+}
+__device__ __forceinline__ double length_squared(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ double length(V3 a) { return sqrt(length_squared(a)); }
+__device__ __forceinline__ V3 to_unit(V3 a) { return a / length(a); }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ bool is_near_zero(V3 a) { return fabs(a.x) < 1e-8 && fabs(a.y) < 1e-8 && fabs(a.z) < 1e-8; }
+// f64::clamp: a NaN argument is returned unchanged
+__device__ __forceinline__ double clampd(double x, double lo, double hi) {
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return x;
+}
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - 2.0 * dot(v, n) * n; }   // src/vector.rs:254-256
+__device__ __forceinline__ V3 refract(V3 r_in, V3 n, double eta) {                       // src/vector.rs:258-264
+    double cos_theta = clampd(dot(-r_in, n), -1.0, 1.0);
+    V3 r_out_perp = eta * (r_in + cos_theta * n);
+    V3 r_out_par = -sqrt(fabs(1.0 - length_squared(r_out_perp))) * n;
+    return r_out_perp + r_out_par;
+}
+__device__ __forceinline__ V3 ld3(const double* p) { return v3(p[0], p[1], p[2]); }
+
+// ---------------------------------------------------------------- RNG
+// Philox4x32-10.  One block gives two uniform doubles.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Uniform doubles of one path: draw i is element (i & 1) of block (i >> 1),
+// counter (pixel, sample, block, 0), key = the 64-bit seed.  A 64-bit word w
+// maps to (w >> 11) * 2^-53.  Every sampling event (the camera sample, each
+// scatter call) starts on a block boundary, so `draw` is the only RNG state
+// a path carries between kernels.
+struct PathRng {
+    uint32_t k0, k1, pixel, sample, draw, cached_block;
+    double cached[2];
+    __device__ __forceinline__ PathRng(uint64_t seed, uint32_t pixel_, uint32_t sample_, uint32_t draw_)
+        : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), pixel(pixel_), sample(sample_), draw(draw_), cached_block(NONE) {
+        cached[0] = cached[1] = 0.0;
+    }
+    __device__ __forceinline__ void begin_event() { draw = (draw + 1u) & ~1u; }
+    __device__ __forceinline__ double next() {
+        uint32_t blk = draw >> 1;
+        if (blk != cached_block) {
+            uint32_t o[4];
+            philox4x32_10(pixel, sample, blk, 0u, k0, k1, o);
+            uint64_t w0 = ((uint64_t)o[1] << 32) | o[0];
+            uint64_t w1 = ((uint64_t)o[3] << 32) | o[2];
+            cached[0] = (double)(w0 >> 11) * 0x1.0p-53;
+            cached[1] = (double)(w1 >> 11) * 0x1.0p-53;
+            cached_block = blk;
+        }
+        double r = (draw & 1u) ? cached[1] : cached[0];
+        ++draw;
+        return r;
+    }
+    __device__ __forceinline__ double range(double lo, double hi) { return next() * (hi - lo) + lo; }
+};
+
+// src/vector.rs:59-81
+__device__ __forceinline__ V3 random_unit(PathRng& rng) {
+    for (;;) {
+        double x = rng.range(-1.0, 1.0);
+        double y = rng.range(-1.0, 1.0);
+        double z = rng.range(-1.0, 1.0);
+        V3 candidate = v3(x, y, z);
+        double lensq = length_squared(candidate);
+        if (1e-160 < lensq && lensq <= 1.0) return candidate / sqrt(lensq);
+    }
+}
+// src/vector.rs:83-95
+__device__ __forceinline__ V3 random_in_unit_disk(PathRng& rng) {
+    for (;;) {
+        double x = rng.range(-1.0, 1.0);
+        double y = rng.range(-1.0, 1.0);
+        V3 candidate = v3(x, y, 0.0);
+        if (length_squared(candidate) < 1.0) return candidate;
+    }
+}
+
+// ---------------------------------------------------------------- box test
+// AABB::hit, src/aabb.rs:55-76, with six true divisions.  The guard at :62
+// uses `==` against NaN and can never fire, so it has no counterpart here.
+__device__ __forceinline__ bool box_fold(double t0x, double t1x, double t0y, double t1y, double t0z, double t1z,
+                                         double tmin, double tmax, double& lowers_max, double& uppers_min) {
+    double lx = clampd(fmin(t0x, t1x), tmin, tmax), ux = clampd(fmax(t0x, t1x), tmin, tmax);
+    double ly = clampd(fmin(t0y, t1y), tmin, tmax), uy = clampd(fmax(t0y, t1y), tmin, tmax);
+    double lz = clampd(fmin(t0z, t1z), tmin, tmax), uz = clampd(fmax(t0z, t1z), tmin, tmax);
+    // fold(NaN, max) / fold(NaN, min): NaN operands drop out
+    lowers_max = fmax(fmax(lx, ly), lz);
+    uppers_min = fmin(fmin(ux, uy), uz);
+    return lowers_max < uppers_min;
+}
+
+__device__ __forceinline__ bool box_hit_exact(const DNode& n, V3 o, V3 d, double tmin, double tmax) {
+    double lo, hi;
+    return box_fold((n.bmin[0] - o.x) / d.x, (n.bmax[0] - o.x) / d.x, (n.bmin[1] - o.y) / d.y, (n.bmax[1] - o.y) / d.y,
+                    (n.bmin[2] - o.z) / d.z, (n.bmax[2] - o.z) / d.z, tmin, tmax, lo, hi);
+}
+// out-of-line copy for the filtered test's rare fallback, so the six
+// divisions stay out of the hot loop's instruction stream and registers
+__device__ __noinline__ bool box_hit_exact_slow(const DNode& n, V3 o, V3 d, double tmin, double tmax) {
+    return box_hit_exact(n, o, d, tmin, tmax);
+}
+
+// Filtered form of the same predicate.  q~ = (b - o) * RN(1/d) differs from
+// the reference's RN((b - o)/d) by at most 3*2^-53 relative (two roundings
+// against one), min/max/clamp are monotone and 1-Lipschitz, and both bounds
+// end up in [tmin, tmax] with tmin > 0.  So if the two folded bounds are
+// further apart than the 2^-50 relative margin the exact predicate has the
+// same outcome; otherwise (about one test in 1e14) the six divisions are
+// done.  A zero direction component gives the same +-inf / NaN either way.
+// Preconditions (checked per ray by filter_ray_ok): finite origin and
+// direction, nonzero components of d within [2^-300, 2^300], box and origin
+// coordinates below 2^300, tmin >= 2^-900.
+constexpr double FILTER_EPS = 0x1.0p-50;
+
+__device__ __forceinline__ bool box_hit_filtered(const DNode& n, V3 o, V3 d, V3 inv, double tmin, double tmax) {
+    double lo, hi;
+    box_fold((n.bmin[0] - o.x) * inv.x, (n.bmax[0] - o.x) * inv.x, (n.bmin[1] - o.y) * inv.y, (n.bmax[1] - o.y) * inv.y,
+             (n.bmin[2] - o.z) * inv.z, (n.bmax[2] - o.z) * inv.z, tmin, tmax, lo, hi);
+    if (lo * (1.0 + FILTER_EPS) < hi * (1.0 - FILTER_EPS)) return true;
+    if (lo * (1.0 - FILTER_EPS) >= hi * (1.0 + FILTER_EPS)) return false;
+    return box_hit_exact_slow(n, o, d, tmin, tmax);
+}
+
+__device__ __forceinline__ bool filter_comp_ok(double d) {
+    double a = fabs(d);
+    return d == 0.0 || (a >= 0x1.0p-300 && a <= 0x1.0p300);
+}
+__device__ __forceinline__ bool filter_ray_ok(V3 o, V3 d, double tmin) {
+    return filter_comp_ok(d.x) && filter_comp_ok(d.y) && filter_comp_ok(d.z) && fabs(o.x) <= 0x1.0p300 &&
+           fabs(o.y) <= 0x1.0p300 && fabs(o.z) <= 0x1.0p300 && tmin >= 0x1.0p-900;
+}
+
+// ---------------------------------------------------------------- primitive tests
+// sphere::hit, src/geometry.rs:204-230 (the t part; the rest of Hit is completed for the winner only)
+__device__ __forceinline__ bool sphere_t(const DSphere& s, V3 o, V3 d, double tmin, double tmax, double& t) {
+    V3 oc = v3(s.c[0], s.c[1], s.c[2]) - o;
+    double a = length_squared(d);
+    double h = dot(d, oc);
+    double c = length_squared(oc) - s.r * s.r;
+    double discriminant = h * h - a * c;
+    if (discriminant < 0.0) return false;
+    double sqrtd = sqrt(discriminant);
+    double root = (h - sqrtd) / a;
+    if (!(tmin < root && root < tmax)) {       // Interval::surrounds, open
+        root = (h + sqrtd) / a;
+        if (!(tmin < root && root < tmax)) return false;
+    }
+    t = root;
+    return true;
+}
+// plane_intersection + uv_hit + quad/triangle::hit, src/geometry.rs:147-190,264-327
+__device__ __forceinline__ bool planar_t(const DPlanar& g, uint32_t kind, V3 o, V3 d, double tmin, double tmax,
+                                         double& t, double& alpha, double& beta) {
+    V3 norm = ld3(g.norm);
+    double denominator = dot(norm, d);
+    if (fabs(denominator) < 1e-10) return false;
+    double tt = (g.d - dot(norm, o)) / denominator;
+    if (!(tmin <= tt && tt <= tmax)) return false;   // Interval::contains, closed
+    V3 p = o + d * tt;
+    V3 qp = p - ld3(g.q);
+    V3 w = ld3(g.w);
+    double al = dot(w, cross(qp, ld3(g.v)));
+    double be = dot(w, cross(ld3(g.u), qp));
+    if (kind == 1u) {   // quad: Interval::UNIT.contains on both
+        if (!(0.0 <= al && al <= 1.0) || !(0.0 <= be && be <= 1.0)) return false;
+    } else {            // triangle
+        if (!(al >= 0.0 && be >= 0.0 && al + be <= 1.0)) return false;
+    }
+    t = tt; alpha = al; beta = be;
+    return true;
+}
+
+}  // namespace rtx
