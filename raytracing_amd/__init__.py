@@ -11,6 +11,15 @@ import os
 
 import numpy as np
 
+try:
+    # PyTorch ships its own copy of the HIP runtime under the same soname as
+    # the system one.  Loading it first makes librtx.so bind to that same copy,
+    # so device pointers and streams can be passed between torch and this
+    # library.  torch is only plumbing here; without it the system runtime is used.
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
+
 from . import scenes
 from .scenes import SURFACE_DTYPE
 
