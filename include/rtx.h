@@ -105,6 +105,7 @@ typedef struct rtx_stats {
     double   ms_total;       /* device time of the call, HIP events */
     double   ms_traverse;    /* summed duration of the traverse kernel launches (0 unless RTX_FLAG_TIME_KERNELS) */
     double   ms_shade;
+    double   ms_generate;    /* generate kernel launches plus the host's termination polls */
 } rtx_stats;
 
 typedef struct rtx_scene rtx_scene;

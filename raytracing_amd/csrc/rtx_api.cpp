@@ -76,16 +76,19 @@ struct rtx_scene {
     // path pool, sized on first use and kept
     size_t pool_slots = 0;
     DevBuf<double> pool_f64;     // 10 arrays
-    DevBuf<uint32_t> pool_u32;   // 5 arrays + 2 queues
+    DevBuf<uint32_t> pool_u32;   // 5 arrays + 2 live queues + 1 free queue
     DevBuf<DRenderCtl> ctl;
     DPool pool{};
     uint32_t* queue[2] = {nullptr, nullptr};
+    uint32_t* free_queue = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> kernel_events;   // reused by RTX_FLAG_TIME_KERNELS, 3 per round
+    uint32_t* h_count = nullptr;             // pinned word the render loop polls
 
     int ensure_pool(size_t slots) {
         if (slots <= pool_slots) return RTX_OK;
         HIP_TRY(pool_f64.resize(10 * slots));
-        HIP_TRY(pool_u32.resize(7 * slots));
+        HIP_TRY(pool_u32.resize(8 * slots));
         HIP_TRY(ctl.resize(1));
         double* f = pool_f64.p;
         pool.ox = f + 0 * slots; pool.oy = f + 1 * slots; pool.oz = f + 2 * slots;
@@ -97,6 +100,7 @@ struct rtx_scene {
         pool.hit_prim = u + 4 * slots;
         queue[0] = u + 5 * slots;
         queue[1] = u + 6 * slots;
+        free_queue = u + 7 * slots;
         pool_slots = slots;
         return RTX_OK;
     }
@@ -243,6 +247,8 @@ void rtx_scene_destroy(rtx_scene* sc) {
     if (!sc) return;
     if (sc->ev0) (void)hipEventDestroy(sc->ev0);
     if (sc->ev1) (void)hipEventDestroy(sc->ev1);
+    for (hipEvent_t e : sc->kernel_events) (void)hipEventDestroy(e);
+    if (sc->h_count) (void)hipHostFree(sc->h_count);
     delete sc;
 }
 
@@ -277,7 +283,7 @@ int rtx_trace_closest(rtx_scene* sc, const double* org, const double* dir, uint6
     launch_rays_to_pool(d_rays.p, d_rays.p + 3 * n, n, sc->pool, s);
     const uint32_t max_blocks = sc->n_cus * 8;
     HIP_TRY(hipEventRecord(sc->ev0, s));
-    launch_traverse(sc->d, sc->pool, nullptr, &sc->ctl.p->count[0], nullptr, n, tmin, tmax, sc->ctl.p,
+    launch_traverse(sc->d, sc->pool, nullptr, &sc->ctl.p->count[0], nullptr, nullptr, n, tmin, tmax, sc->ctl.p,
                     (flags & RTX_FLAG_COUNT_WORK) != 0, (flags & RTX_FLAG_EXACT_DIVIDE) != 0, max_blocks, s);
     HIP_TRY(hipEventRecord(sc->ev1, s));
     launch_user_ids(sc->d.prims, sc->pool.hit_prim, n, s);
@@ -364,17 +370,24 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     const bool time_kernels = (flags & RTX_FLAG_TIME_KERNELS) != 0;
     const DCamera dcam = to_dcamera(cam);
 
+    // Round structure (all on one stream, no host round trip inside a round):
+    //   generate : start new paths in the free slots, append them to queue[cur]
+    //   traverse : closest hit for every slot in queue[cur]
+    //   shade    : scatter / terminate; survivors -> queue[nxt], finished slots -> free queue
+    // The first generate sees every slot free.
     DRenderCtl h{};
-    h.next_path = slots;
+    h.next_path = 0;
     h.total_paths = total;
-    h.count[0] = slots;
+    h.n_free = slots;
     HIP_TRY(hipMemcpyAsync(sc->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(sc->ev0, s));
-    launch_generate(dcam, sc->pool, slots, seed, spp_begin, sc->queue[0], max_blocks, s);
+    launch_iota(sc->free_queue, slots, s);
+    DRenderCtl* ctl = sc->ctl.p;
 
-    std::vector<hipEvent_t> evs;   // only with RTX_FLAG_TIME_KERNELS: 3 per round
-    uint32_t* h_count = nullptr;
-    HIP_TRY(hipHostMalloc((void**)&h_count, sizeof(uint32_t), hipHostMallocDefault));
+    std::vector<hipEvent_t>& evs = sc->kernel_events;   // only with RTX_FLAG_TIME_KERNELS: 3 per round
+    size_t n_evs = 0;
+    if (!sc->h_count) HIP_TRY(hipHostMalloc((void**)&sc->h_count, sizeof(uint32_t), hipHostMallocDefault));
+    uint32_t* h_count = sc->h_count;
     *h_count = slots;
     uint64_t iters = 0;
     int cur = 0;
@@ -383,23 +396,32 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         const int nxt = cur ^ 1;
         hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
         if (time_kernels) {
-            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) {
+            while (evs.size() < n_evs + 3) {
+                hipEvent_t e = nullptr;
+                if (hipEventCreate(&e) != hipSuccess) break;
+                evs.push_back(e);
+            }
+            if (evs.size() < n_evs + 3) {
                 status = fail(RTX_ERR_HIP, "hipEventCreate failed");
                 break;
             }
-            evs.push_back(e0); evs.push_back(e1); evs.push_back(e2);
-            (void)hipEventRecord(e0, s);
+            e0 = evs[n_evs]; e1 = evs[n_evs + 1]; e2 = evs[n_evs + 2];
+            n_evs += 3;
         }
-        launch_traverse(sc->d, sc->pool, sc->queue[cur], &sc->ctl.p->count[cur], &sc->ctl.p->count[nxt], slots, 0.001,
-                        INFINITY, sc->ctl.p, count_work, exact, max_blocks, s);   // Interval(0.001, inf), camera.rs:194
+        launch_generate(dcam, sc->pool, sc->free_queue, &ctl->n_free, sc->queue[cur], &ctl->count[cur], slots, ctl, seed, spp_begin,
+                        max_blocks, s);
+        if (time_kernels) (void)hipEventRecord(e0, s);
+        // traverse also clears the two queue lengths that shade appends to
+        launch_traverse(sc->d, sc->pool, sc->queue[cur], &ctl->count[cur], &ctl->count[nxt], &ctl->n_free, slots, 0.001, INFINITY,
+                        ctl, count_work, exact, max_blocks, s);   // Interval(0.001, inf), camera.rs:194
         if (time_kernels) (void)hipEventRecord(e1, s);
-        launch_shade(sc->d, dcam, sc->pool, sc->queue[cur], &sc->ctl.p->count[cur], sc->queue[nxt], &sc->ctl.p->count[nxt],
-                     slots, sc->ctl.p, seed, spp_begin, d_accum, max_blocks, s);
+        launch_shade(sc->d, dcam, sc->pool, sc->queue[cur], &ctl->count[cur], sc->queue[nxt], &ctl->count[nxt], sc->free_queue,
+                     &ctl->n_free, slots, seed, d_accum, max_blocks, s);
         if (time_kernels) (void)hipEventRecord(e2, s);
         ++iters;
-        cur = nxt;
         if (iters % check_every == 0) {
-            hipError_t e = hipMemcpyAsync(h_count, &sc->ctl.p->count[cur], sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+            // the round is over when nothing was traced: no survivors and no paths left to start
+            hipError_t e = hipMemcpyAsync(h_count, &ctl->count[cur], sizeof(uint32_t), hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (e != hipSuccess) {
                 status = fail(RTX_ERR_HIP, std::string("render loop: ") + hipGetErrorString(e));
@@ -407,8 +429,8 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
             }
             if (*h_count == 0) break;
         }
+        cur = nxt;
     }
-    (void)hipHostFree(h_count);
     if (status == RTX_OK) {
         hipError_t e = hipEventRecord(sc->ev1, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -421,16 +443,17 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         stats->ms_total = ms;
         stats->paths = total;
         stats->iterations = iters;
-        for (size_t i = 0; i + 2 < evs.size(); i += 3) {
-            float a = 0.f, b = 0.f;
+        for (size_t i = 0; i + 2 < n_evs; i += 3) {
+            float a = 0.f, b = 0.f, g = 0.f;
             (void)hipEventElapsedTime(&a, evs[i], evs[i + 1]);
             (void)hipEventElapsedTime(&b, evs[i + 1], evs[i + 2]);
+            (void)hipEventElapsedTime(&g, i == 0 ? sc->ev0 : evs[i - 1], evs[i]);   // includes the host's poll every few rounds
             stats->ms_traverse += a;
             stats->ms_shade += b;
+            stats->ms_generate += g;
         }
         status = read_counters(sc, s, stats);
     }
-    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     return status;
 }
 

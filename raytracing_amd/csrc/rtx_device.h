@@ -82,6 +82,8 @@ struct DRenderCtl {
     unsigned long long rays;         // closest-hit queries issued so far
     unsigned long long node_visits, sphere_tests, planar_tests;
     uint32_t count[2];               // live entries of the two slot queues
+    uint32_t n_free;                 // entries of the free-slot queue
+    uint32_t _pad;
 };
 
 // ---------------------------------------------------------------- Vector3 (src/vector.rs)

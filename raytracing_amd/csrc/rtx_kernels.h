@@ -4,16 +4,18 @@
 
 namespace rtx {
 
-void launch_generate(const DCamera& cam, const DPool& pool, uint32_t n_slots, uint64_t seed, uint32_t spp_begin,
-                     uint32_t* queue, uint32_t max_blocks, hipStream_t s);
+void launch_generate(const DCamera& cam, const DPool& pool, const uint32_t* free_queue, const uint32_t* n_free, uint32_t* queue_out,
+                     uint32_t* count_out, uint64_t max_count, DRenderCtl* ctl, uint64_t seed, uint32_t spp_begin,
+                     uint32_t max_blocks, hipStream_t s);
+void launch_iota(uint32_t* q, uint32_t n, hipStream_t s);
 void launch_primary_rays(const DCamera& cam, uint64_t seed, uint32_t sample, uint32_t npix, double* org, double* dir,
                          uint32_t max_blocks, hipStream_t s);
-void launch_traverse(const DScene& sc, const DPool& pool, const uint32_t* queue, const uint32_t* count_ptr, uint32_t* zero_me,
-                     uint64_t max_count, double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool exact,
+void launch_traverse(const DScene& sc, const DPool& pool, const uint32_t* queue, const uint32_t* count_ptr, uint32_t* zero_a,
+                     uint32_t* zero_b, uint64_t max_count, double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool exact,
                      uint32_t max_blocks, hipStream_t s);
 void launch_shade(const DScene& sc, const DCamera& cam, const DPool& pool, const uint32_t* queue_in, const uint32_t* count_in,
-                  uint32_t* queue_out, uint32_t* count_out, uint64_t max_count, DRenderCtl* ctl, uint64_t seed,
-                  uint32_t spp_begin, double* accum, uint32_t max_blocks, hipStream_t s);
+                  uint32_t* queue_out, uint32_t* count_out, uint32_t* free_queue, uint32_t* n_free, uint64_t max_count,
+                  uint64_t seed, double* accum, uint32_t max_blocks, hipStream_t s);
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s);
 void launch_quantize(const double* in, uint64_t n, uint8_t* out, hipStream_t s);
 void launch_rays_to_pool(const double* org, const double* dir, uint64_t n, const DPool& pool, hipStream_t s);

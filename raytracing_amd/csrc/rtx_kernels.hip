@@ -58,12 +58,46 @@ __device__ __forceinline__ void store_new_path(const DPool& pool, uint32_t slot,
     pool.depth[slot] = 0u;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_generate(DCamera cam, DPool pool, uint32_t n_slots, uint64_t seed,
-                                                    uint32_t spp_begin, uint32_t* queue) {
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_slots; i += gridDim.x * BLOCK) {
-        store_new_path(pool, i, cam, seed, spp_begin, i);
-        queue[i] = i;
+// Starts new paths in the slots the shade kernel has freed (or, on the first
+// round, in every slot): slot free_queue[i] gets the next unstarted
+// (pixel, sample) pair and is appended to the live queue.  One atomic per
+// wave on the path counter and one on the queue length.
+__global__ __launch_bounds__(BLOCK) void k_generate(DCamera cam, DPool pool, const uint32_t* free_queue, const uint32_t* n_free_ptr,
+                                                    uint32_t* queue_out, uint32_t* count_out, DRenderCtl* ctl, uint64_t seed,
+                                                    uint32_t spp_begin) {
+    const uint32_t n_free = *n_free_ptr;
+    const uint32_t lane = lane_id();
+    const uint32_t stride = gridDim.x * BLOCK;
+    const uint32_t rounds = (n_free + stride - 1) / stride;   // wave-uniform bound: every lane reaches the ballots
+    const unsigned long long total = ctl->total_paths;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        uint32_t i = r * stride + blockIdx.x * BLOCK + threadIdx.x;
+        bool want = i < n_free;
+        unsigned long long wmask = __ballot(want);
+        if (!wmask) continue;
+        uint32_t leader = __ffsll((long long)wmask) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(&ctl->next_path, (unsigned long long)__popcll(wmask));
+        base = __shfl(base, leader);
+        unsigned long long g = base + __popcll(wmask & ((1ull << lane) - 1ull));
+        bool start = want && g < total;
+        uint32_t slot = 0;
+        if (start) {
+            slot = free_queue[i];
+            store_new_path(pool, slot, cam, seed, spp_begin, g);
+        }
+        unsigned long long smask = __ballot(start);
+        if (smask) {
+            uint32_t sl = __ffsll((long long)smask) - 1;
+            uint32_t qbase = 0;
+            if (lane == sl) qbase = atomicAdd(count_out, (uint32_t)__popcll(smask));
+            qbase = __shfl(qbase, sl);
+            if (start) queue_out[qbase + __popcll(smask & ((1ull << lane) - 1ull))] = slot;
+        }
     }
+}
+__global__ __launch_bounds__(BLOCK) void k_iota(uint32_t* q, uint32_t n) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) q[i] = i;
 }
 
 // Primary rays only, for the parity API (rays laid out [n][3]).
@@ -134,10 +168,12 @@ __device__ __forceinline__ void closest_hit(const DScene& sc, V3 o, V3 d, double
 
 template <bool COUNT, bool EXACT>
 __global__ __launch_bounds__(BLOCK) void k_traverse(DScene sc, DPool pool, const uint32_t* queue, const uint32_t* count_ptr,
-                                                    uint32_t* zero_me, double tmin, double tmax, DRenderCtl* ctl) {
+                                                    uint32_t* zero_a, uint32_t* zero_b, double tmin, double tmax, DRenderCtl* ctl) {
     const uint32_t count = *count_ptr;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (zero_me) *zero_me = 0u;
+        // lengths of the queues the following shade / generate kernels append to
+        if (zero_a) *zero_a = 0u;
+        if (zero_b) *zero_b = 0u;
         if (ctl) atomicAdd(&ctl->rays, (unsigned long long)count);
     }
     uint32_t c_nodes = 0, c_sph = 0, c_pln = 0;
@@ -178,7 +214,7 @@ __device__ __forceinline__ double reflectance(double cos_theta, double refractio
 // attenuations, associated from the other end.
 __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DPool pool, const uint32_t* queue_in,
                                                  const uint32_t* count_in, uint32_t* queue_out, uint32_t* count_out,
-                                                 DRenderCtl* ctl, uint64_t seed, uint32_t spp_begin, double* accum) {
+                                                 uint32_t* free_queue, uint32_t* n_free, uint64_t seed, double* accum) {
     const uint32_t count = *count_in;
     const uint32_t lane = lane_id();
     const uint32_t stride = gridDim.x * BLOCK;
@@ -188,7 +224,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DPool p
         uint32_t i = r * stride + blockIdx.x * BLOCK + threadIdx.x;
         bool active = i < count;
         bool alive = false;     // slot goes into the next queue
-        bool finished = false;  // path ended: slot is free for a new path
         uint32_t slot = 0;
         if (active) {
             slot = queue_in[i];
@@ -200,7 +235,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DPool p
             if (prim == NONE) {
                 radiance = beta * ld3(cam.background);   // camera.rs:207
                 add = true;
-                finished = true;
             } else {
                 V3 o = v3(pool.ox[slot], pool.oy[slot], pool.oz[slot]);
                 V3 d = v3(pool.dx[slot], pool.dy[slot], pool.dz[slot]);
@@ -250,20 +284,22 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DPool p
                 rng.begin_event();
                 bool scattered = false;
                 V3 nd = v3(0.0, 0.0, 0.0), att = v3(1.0, 1.0, 1.0);
-                if (m.kind == 0u) {            // lambertian, material.rs:61-73
-                    V3 direction = n + random_unit(rng);
-                    if (is_near_zero(direction)) direction = n;
-                    nd = direction;
+                if (m.kind <= 1u) {
+                    // Lambertian and Metal both start with Vector3::random_unit()
+                    // (material.rs:62, :86); one shared rejection loop for the wave
+                    V3 ru = random_unit(rng);
                     att = ld3(m.rgb);
-                    scattered = true;
-                } else if (m.kind == 1u) {     // metal, material.rs:84-96
-                    V3 reflected = reflect(d, n);
-                    V3 fuzz = random_unit(rng) * m.param;
-                    V3 fuzzed = to_unit(reflected) + fuzz;
-                    if (dot(fuzzed, n) > 0.0) {
-                        nd = fuzzed;
-                        att = ld3(m.rgb);
+                    if (m.kind == 0u) {        // lambertian, material.rs:61-73
+                        V3 direction = n + ru;
+                        if (is_near_zero(direction)) direction = n;
+                        nd = direction;
                         scattered = true;
+                    } else {                   // metal, material.rs:84-96
+                        V3 reflected = reflect(d, n);
+                        V3 fuzz = ru * m.param;
+                        V3 fuzzed = to_unit(reflected) + fuzz;
+                        nd = fuzzed;
+                        scattered = dot(fuzzed, n) > 0.0;
                     }
                 } else if (m.kind == 2u) {     // dielectric, material.rs:108-130
                     V3 r_in = to_unit(d);
@@ -284,8 +320,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DPool p
                     pool.draw[slot] = rng.draw;
                     pool.depth[slot] = depth;
                     alive = true;
-                } else {
-                    finished = true;
                 }
             }
             if (add) {
@@ -295,31 +329,25 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DPool p
                 if (radiance.z != 0.0) unsafeAtomicAdd(px + 2, radiance.z);
             }
         }
-        // restart finished slots on the next unstarted paths (one atomic per wave)
-        unsigned long long fmask = __ballot(finished);
-        if (fmask) {
-            uint32_t n = __popcll(fmask);
-            uint32_t leader = __ffsll((long long)fmask) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(&ctl->next_path, (unsigned long long)n);
-            base = __shfl(base, leader);
-            if (finished) {
-                unsigned long long g = base + __popcll(fmask & ((1ull << lane) - 1ull));
-                if (g < ctl->total_paths) {
-                    store_new_path(pool, slot, cam, seed, spp_begin, g);
-                    alive = true;
-                }
-            }
-        }
-        // compact live slots into the next queue
+        // compaction: live slots into the next queue, finished slots into the
+        // free queue (64-wide ballot + prefix popcount, one atomic per wave and queue)
+        const bool finished = active && !alive;
         unsigned long long amask = __ballot(alive);
+        unsigned long long fmask = __ballot(finished);
+        const unsigned long long below = (1ull << lane) - 1ull;
         if (amask) {
-            uint32_t n = __popcll(amask);
             uint32_t leader = __ffsll((long long)amask) - 1;
             uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(count_out, n);
+            if (lane == leader) base = atomicAdd(count_out, (uint32_t)__popcll(amask));
             base = __shfl(base, leader);
-            if (alive) queue_out[base + __popcll(amask & ((1ull << lane) - 1ull))] = slot;
+            if (alive) queue_out[base + __popcll(amask & below)] = slot;
+        }
+        if (fmask) {
+            uint32_t leader = __ffsll((long long)fmask) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(n_free, (uint32_t)__popcll(fmask));
+            base = __shfl(base, leader);
+            if (finished) free_queue[base + __popcll(fmask & below)] = slot;
         }
     }
 }
@@ -375,31 +403,36 @@ static inline uint32_t grid_for(uint64_t n, uint32_t max_blocks) {
     return (uint32_t)b;
 }
 
-void launch_generate(const DCamera& cam, const DPool& pool, uint32_t n_slots, uint64_t seed, uint32_t spp_begin,
-                     uint32_t* queue, uint32_t max_blocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(n_slots, max_blocks)), dim3(BLOCK), 0, s, cam, pool, n_slots, seed, spp_begin, queue);
+void launch_generate(const DCamera& cam, const DPool& pool, const uint32_t* free_queue, const uint32_t* n_free, uint32_t* queue_out,
+                     uint32_t* count_out, uint64_t max_count, DRenderCtl* ctl, uint64_t seed, uint32_t spp_begin,
+                     uint32_t max_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(max_count, max_blocks)), dim3(BLOCK), 0, s, cam, pool, free_queue, n_free, queue_out,
+                       count_out, ctl, seed, spp_begin);
+}
+void launch_iota(uint32_t* q, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, q, n);
 }
 void launch_primary_rays(const DCamera& cam, uint64_t seed, uint32_t sample, uint32_t npix, double* org, double* dir,
                          uint32_t max_blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_primary_rays, dim3(grid_for(npix, max_blocks)), dim3(BLOCK), 0, s, cam, seed, sample, npix, org, dir);
 }
-void launch_traverse(const DScene& sc, const DPool& pool, const uint32_t* queue, const uint32_t* count_ptr, uint32_t* zero_me,
-                     uint64_t max_count, double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool exact,
+void launch_traverse(const DScene& sc, const DPool& pool, const uint32_t* queue, const uint32_t* count_ptr, uint32_t* zero_a,
+                     uint32_t* zero_b, uint64_t max_count, double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool exact,
                      uint32_t max_blocks, hipStream_t s) {
     dim3 g(grid_for(max_count, max_blocks)), b(BLOCK);
     if (count_work) {
-        if (exact) hipLaunchKernelGGL((k_traverse<true, true>), g, b, 0, s, sc, pool, queue, count_ptr, zero_me, tmin, tmax, ctl);
-        else hipLaunchKernelGGL((k_traverse<true, false>), g, b, 0, s, sc, pool, queue, count_ptr, zero_me, tmin, tmax, ctl);
+        if (exact) hipLaunchKernelGGL((k_traverse<true, true>), g, b, 0, s, sc, pool, queue, count_ptr, zero_a, zero_b, tmin, tmax, ctl);
+        else hipLaunchKernelGGL((k_traverse<true, false>), g, b, 0, s, sc, pool, queue, count_ptr, zero_a, zero_b, tmin, tmax, ctl);
     } else {
-        if (exact) hipLaunchKernelGGL((k_traverse<false, true>), g, b, 0, s, sc, pool, queue, count_ptr, zero_me, tmin, tmax, ctl);
-        else hipLaunchKernelGGL((k_traverse<false, false>), g, b, 0, s, sc, pool, queue, count_ptr, zero_me, tmin, tmax, ctl);
+        if (exact) hipLaunchKernelGGL((k_traverse<false, true>), g, b, 0, s, sc, pool, queue, count_ptr, zero_a, zero_b, tmin, tmax, ctl);
+        else hipLaunchKernelGGL((k_traverse<false, false>), g, b, 0, s, sc, pool, queue, count_ptr, zero_a, zero_b, tmin, tmax, ctl);
     }
 }
 void launch_shade(const DScene& sc, const DCamera& cam, const DPool& pool, const uint32_t* queue_in, const uint32_t* count_in,
-                  uint32_t* queue_out, uint32_t* count_out, uint64_t max_count, DRenderCtl* ctl, uint64_t seed,
-                  uint32_t spp_begin, double* accum, uint32_t max_blocks, hipStream_t s) {
+                  uint32_t* queue_out, uint32_t* count_out, uint32_t* free_queue, uint32_t* n_free, uint64_t max_count,
+                  uint64_t seed, double* accum, uint32_t max_blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_shade, dim3(grid_for(max_count, max_blocks)), dim3(BLOCK), 0, s, sc, cam, pool, queue_in, count_in,
-                       queue_out, count_out, ctl, seed, spp_begin, accum);
+                       queue_out, count_out, free_queue, n_free, seed, accum);
 }
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_scale, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, in, n, scale, out);
