@@ -73,35 +73,35 @@ struct rtx_scene {
     DevBuf<DPlanar> planars;
     DevBuf<DPrimInfo> prims;
     DevBuf<DMaterial> materials;
-    // path pool, sized on first use and kept
-    size_t pool_slots = 0;
-    DevBuf<double> pool_f64;     // 10 arrays
-    DevBuf<uint32_t> pool_u32;   // 5 arrays + 2 live queues + 1 free queue
+    // path state (two buffers, ping-pong) and hit records, sized on first use and kept
+    size_t capacity = 0;
+    DevBuf<double> buf_f64;     // 2 x 9 state arrays + hit_t
+    DevBuf<uint32_t> buf_u32;   // 2 x 4 state arrays + hit_prim
     DevBuf<DRenderCtl> ctl;
-    DPool pool{};
-    uint32_t* queue[2] = {nullptr, nullptr};
-    uint32_t* free_queue = nullptr;
+    DState state[2]{};
+    DHits hits{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kernel_events;   // reused by RTX_FLAG_TIME_KERNELS, 3 per round
     uint32_t* h_count = nullptr;             // pinned word the render loop polls
 
-    int ensure_pool(size_t slots) {
-        if (slots <= pool_slots) return RTX_OK;
-        HIP_TRY(pool_f64.resize(10 * slots));
-        HIP_TRY(pool_u32.resize(8 * slots));
+    int ensure_capacity(size_t n) {
+        if (n <= capacity) return RTX_OK;
+        HIP_TRY(buf_f64.resize(19 * n));
+        HIP_TRY(buf_u32.resize(9 * n));
         HIP_TRY(ctl.resize(1));
-        double* f = pool_f64.p;
-        pool.ox = f + 0 * slots; pool.oy = f + 1 * slots; pool.oz = f + 2 * slots;
-        pool.dx = f + 3 * slots; pool.dy = f + 4 * slots; pool.dz = f + 5 * slots;
-        pool.bx = f + 6 * slots; pool.by = f + 7 * slots; pool.bz = f + 8 * slots;
-        pool.hit_t = f + 9 * slots;
-        uint32_t* u = pool_u32.p;
-        pool.pixel = u + 0 * slots; pool.sample = u + 1 * slots; pool.draw = u + 2 * slots; pool.depth = u + 3 * slots;
-        pool.hit_prim = u + 4 * slots;
-        queue[0] = u + 5 * slots;
-        queue[1] = u + 6 * slots;
-        free_queue = u + 7 * slots;
-        pool_slots = slots;
+        double* f = buf_f64.p;
+        uint32_t* u = buf_u32.p;
+        for (int b = 0; b < 2; ++b) {
+            DState& st = state[b];
+            st.ox = f; st.oy = f + n; st.oz = f + 2 * n; st.dx = f + 3 * n; st.dy = f + 4 * n; st.dz = f + 5 * n;
+            st.bx = f + 6 * n; st.by = f + 7 * n; st.bz = f + 8 * n;
+            f += 9 * n;
+            st.pixel = u; st.sample = u + n; st.draw = u + 2 * n; st.depth = u + 3 * n;
+            u += 4 * n;
+        }
+        hits.t = f;
+        hits.prim = u;
+        capacity = n;
         return RTX_OK;
     }
 };
@@ -270,7 +270,7 @@ int rtx_trace_closest(rtx_scene* sc, const double* org, const double* dir, uint6
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (n == 0) return RTX_OK;
     HIP_TRY(hipSetDevice(sc->device));
-    int rc = sc->ensure_pool((size_t)n);
+    int rc = sc->ensure_capacity((size_t)n);
     if (rc != RTX_OK) return rc;
     hipStream_t s = nullptr;
     DevBuf<double> d_rays;
@@ -278,18 +278,19 @@ int rtx_trace_closest(rtx_scene* sc, const double* org, const double* dir, uint6
     HIP_TRY(hipMemcpyAsync(d_rays.p, org, 3 * n * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_rays.p + 3 * n, dir, 3 * n * sizeof(double), hipMemcpyHostToDevice, s));
     DRenderCtl h{};
-    h.count[0] = (uint32_t)n;
+    h.count_live = (uint32_t)n;
+    h.rays = n;
     HIP_TRY(hipMemcpyAsync(sc->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
-    launch_rays_to_pool(d_rays.p, d_rays.p + 3 * n, n, sc->pool, s);
-    const uint32_t max_blocks = sc->n_cus * 8;
+    launch_rays_to_state(d_rays.p, d_rays.p + 3 * n, n, sc->state[0], s);
+    const uint32_t max_blocks = sc->n_cus * env_u32("RTX_BLOCKS_PER_CU", 8);
     HIP_TRY(hipEventRecord(sc->ev0, s));
-    launch_traverse(sc->d, sc->pool, nullptr, &sc->ctl.p->count[0], nullptr, nullptr, n, tmin, tmax, sc->ctl.p,
+    launch_traverse(sc->d, sc->state[0], sc->hits, &sc->ctl.p->count_live, &sc->ctl.p->next_ray, n, tmin, tmax, sc->ctl.p,
                     (flags & RTX_FLAG_COUNT_WORK) != 0, (flags & RTX_FLAG_EXACT_DIVIDE) != 0, max_blocks, s);
     HIP_TRY(hipEventRecord(sc->ev1, s));
-    launch_user_ids(sc->d.prims, sc->pool.hit_prim, n, s);
+    launch_user_ids(sc->d.prims, sc->hits.prim, n, s);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out_id, sc->pool.hit_prim, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(out_t, sc->pool.hit_t, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_id, sc->hits.prim, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_t, sc->hits.t, n * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (uint64_t i = 0; i < n; ++i)
         if (out_id[i] == RTX_NONE) out_t[i] = INFINITY;
@@ -361,7 +362,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
 
     const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 22);
     const uint32_t slots = (uint32_t)(total < want ? total : want);
-    rc = sc->ensure_pool(slots);
+    rc = sc->ensure_capacity(slots);
     if (rc != RTX_OK) return rc;
     const uint32_t max_blocks = sc->n_cus * env_u32("RTX_BLOCKS_PER_CU", 8);
     const uint32_t check_every = env_u32("RTX_CHECK_EVERY", 4);
@@ -370,18 +371,14 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     const bool time_kernels = (flags & RTX_FLAG_TIME_KERNELS) != 0;
     const DCamera dcam = to_dcamera(cam);
 
-    // Round structure (all on one stream, no host round trip inside a round):
-    //   generate : start new paths in the free slots, append them to queue[cur]
-    //   traverse : closest hit for every slot in queue[cur]
-    //   shade    : scatter / terminate; survivors -> queue[nxt], finished slots -> free queue
-    // The first generate sees every slot free.
+    // Round r works on state buffer r & 1 (all on one stream, no host round trip inside a round):
+    //   generate : start new paths behind the survivors until the buffer is full
+    //   traverse : closest hit of every ray in the buffer
+    //   shade    : scatter / terminate; survivors are written densely into the other buffer
     DRenderCtl h{};
-    h.next_path = 0;
     h.total_paths = total;
-    h.n_free = slots;
     HIP_TRY(hipMemcpyAsync(sc->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(sc->ev0, s));
-    launch_iota(sc->free_queue, slots, s);
     DRenderCtl* ctl = sc->ctl.p;
 
     std::vector<hipEvent_t>& evs = sc->kernel_events;   // only with RTX_FLAG_TIME_KERNELS: 3 per round
@@ -390,10 +387,9 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     uint32_t* h_count = sc->h_count;
     *h_count = slots;
     uint64_t iters = 0;
-    int cur = 0;
     int status = RTX_OK;
     for (;;) {
-        const int nxt = cur ^ 1;
+        const uint32_t cur = (uint32_t)(iters & 1u), nxt = cur ^ 1u;
         hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
         if (time_kernels) {
             while (evs.size() < n_evs + 3) {
@@ -408,20 +404,18 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
             e0 = evs[n_evs]; e1 = evs[n_evs + 1]; e2 = evs[n_evs + 2];
             n_evs += 3;
         }
-        launch_generate(dcam, sc->pool, sc->free_queue, &ctl->n_free, sc->queue[cur], &ctl->count[cur], slots, ctl, seed, spp_begin,
-                        max_blocks, s);
+        launch_generate(dcam, sc->state[cur], slots, ctl, cur, seed, spp_begin, max_blocks, s);
         if (time_kernels) (void)hipEventRecord(e0, s);
-        // traverse also clears the two queue lengths that shade appends to
-        launch_traverse(sc->d, sc->pool, sc->queue[cur], &ctl->count[cur], &ctl->count[nxt], &ctl->n_free, slots, 0.001, INFINITY,
-                        ctl, count_work, exact, max_blocks, s);   // Interval(0.001, inf), camera.rs:194
+        launch_traverse(sc->d, sc->state[cur], sc->hits, &ctl->count_live, &ctl->next_ray, slots, 0.001, INFINITY, ctl,
+                        count_work, exact, max_blocks, s);   // Interval(0.001, inf), camera.rs:194
         if (time_kernels) (void)hipEventRecord(e1, s);
-        launch_shade(sc->d, dcam, sc->pool, sc->queue[cur], &ctl->count[cur], sc->queue[nxt], &ctl->count[nxt], sc->free_queue,
-                     &ctl->n_free, slots, seed, d_accum, max_blocks, s);
+        launch_shade(sc->d, dcam, sc->state[cur], sc->hits, &ctl->count_live, sc->state[nxt], &ctl->count_surv[nxt], slots, seed,
+                     d_accum, max_blocks, s);
         if (time_kernels) (void)hipEventRecord(e2, s);
         ++iters;
         if (iters % check_every == 0) {
-            // the round is over when nothing was traced: no survivors and no paths left to start
-            hipError_t e = hipMemcpyAsync(h_count, &ctl->count[cur], sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+            // finished when a round had nothing to trace: no survivors and no paths left to start
+            hipError_t e = hipMemcpyAsync(h_count, &ctl->count_live, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (e != hipSuccess) {
                 status = fail(RTX_ERR_HIP, std::string("render loop: ") + hipGetErrorString(e));
@@ -429,7 +423,6 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
             }
             if (*h_count == 0) break;
         }
-        cur = nxt;
     }
     if (status == RTX_OK) {
         hipError_t e = hipEventRecord(sc->ev1, s);

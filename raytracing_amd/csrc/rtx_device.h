@@ -58,14 +58,20 @@ struct DScene {
     uint32_t filter_ok;   // every box coordinate is finite and small enough for the filtered box test
 };
 
-// Path pool: one slot per path in flight, struct-of-arrays so that a wave's
-// loads and stores of one field are contiguous.
-struct DPool {
+// State of the paths in flight, struct-of-arrays.  Entry i of every array
+// belongs to the i-th live path of the current round; the shade kernel writes
+// the survivors of a round densely into the other buffer (stream compaction),
+// so every kernel reads and writes these arrays with consecutive lanes on
+// consecutive addresses.
+struct DState {
     double *ox, *oy, *oz, *dx, *dy, *dz;   // current ray (src/ray.rs:4-7)
     double *bx, *by, *bz;                  // product of attenuations so far
     uint32_t *pixel, *sample, *draw, *depth;
-    uint32_t* hit_prim;                    // closest-hit record of the current ray
-    double* hit_t;
+};
+// Closest-hit record of ray i of the current round.
+struct DHits {
+    uint32_t* prim;
+    double* t;
 };
 
 struct DCamera {   // InitializedCamera, src/camera.rs:28-43
@@ -75,15 +81,17 @@ struct DCamera {   // InitializedCamera, src/camera.rs:28-43
     double center[3], pixel00_loc[3], pixel_du[3], pixel_dv[3], defocus_disk_u[3], defocus_disk_v[3];
 };
 
-// Control block of one render call (device memory).
+// Control block of one render call (device memory).  Words that one kernel
+// reads while another word of the same meaning is written are kept twice,
+// indexed by round parity.
 struct DRenderCtl {
-    unsigned long long next_path;    // next unstarted (pixel, sample) index
+    unsigned long long next_path[2];   // next unstarted (pixel, sample) index
     unsigned long long total_paths;
-    unsigned long long rays;         // closest-hit queries issued so far
+    unsigned long long rays;           // closest-hit queries issued so far
     unsigned long long node_visits, sphere_tests, planar_tests;
-    uint32_t count[2];               // live entries of the two slot queues
-    uint32_t n_free;                 // entries of the free-slot queue
-    uint32_t _pad;
+    uint32_t count_live;               // rays of the current round
+    uint32_t count_surv[2];            // survivors written into state buffer [parity]
+    uint32_t next_ray;                 // work counter of the traverse kernel
 };
 
 // ---------------------------------------------------------------- Vector3 (src/vector.rs)
@@ -208,45 +216,68 @@ __device__ __forceinline__ bool box_fold(double t0x, double t1x, double t0y, dou
     return lowers_max < uppers_min;
 }
 
-__device__ __forceinline__ bool box_hit_exact(const DNode& n, V3 o, V3 d, double tmin, double tmax) {
+__device__ __forceinline__ bool box_hit_exact(const double bmin[3], const double bmax[3], V3 o, V3 d, double tmin, double tmax) {
     double lo, hi;
-    return box_fold((n.bmin[0] - o.x) / d.x, (n.bmax[0] - o.x) / d.x, (n.bmin[1] - o.y) / d.y, (n.bmax[1] - o.y) / d.y,
-                    (n.bmin[2] - o.z) / d.z, (n.bmax[2] - o.z) / d.z, tmin, tmax, lo, hi);
+    return box_fold((bmin[0] - o.x) / d.x, (bmax[0] - o.x) / d.x, (bmin[1] - o.y) / d.y, (bmax[1] - o.y) / d.y,
+                    (bmin[2] - o.z) / d.z, (bmax[2] - o.z) / d.z, tmin, tmax, lo, hi);
 }
 // out-of-line copy for the filtered test's rare fallback, so the six
 // divisions stay out of the hot loop's instruction stream and registers
-__device__ __noinline__ bool box_hit_exact_slow(const DNode& n, V3 o, V3 d, double tmin, double tmax) {
-    return box_hit_exact(n, o, d, tmin, tmax);
+__device__ __noinline__ bool box_hit_exact_slow(const double bmin[3], const double bmax[3], V3 o, V3 d, double tmin, double tmax) {
+    return box_hit_exact(bmin, bmax, o, d, tmin, tmax);
 }
 
-// Filtered form of the same predicate.  q~ = (b - o) * RN(1/d) differs from
-// the reference's RN((b - o)/d) by at most 3*2^-53 relative (two roundings
-// against one), min/max/clamp are monotone and 1-Lipschitz, and both bounds
-// end up in [tmin, tmax] with tmin > 0.  So if the two folded bounds are
-// further apart than the 2^-50 relative margin the exact predicate has the
-// same outcome; otherwise (about one test in 1e14) the six divisions are
-// done.  A zero direction component gives the same +-inf / NaN either way.
-// Preconditions (checked per ray by filter_ray_ok): finite origin and
-// direction, nonzero components of d within [2^-300, 2^300], box and origin
-// coordinates below 2^300, tmin >= 2^-900.
+// Filtered form of the same predicate.
+//
+// With NaN-free operands clamp commutes with max/min (it is monotone), so the
+// reference's  max_i clamp(lower_i) < min_i clamp(upper_i)  equals, for
+// lo* = max_i lower_i and hi* = min_i upper_i and tmin < tmax,
+//     hi* > tmin  &&  lo* < tmax  &&  lo* < hi*.
+// The filter evaluates lo, hi with q~ = (b - o) * RN(1/d) instead of
+// RN((b - o)/d).  q~ differs from the reference quotient by at most
+// 3 * 2^-53 relative (two roundings against one) and max/min preserve that
+// bound, so each of the three comparisons is decided for certain when its two
+// sides are further apart than the 2^-50 relative margin; if any comparison
+// that matters is inside the margin (about one test in 1e13) the six true
+// divisions are done instead.  Preconditions, checked once per ray by
+// filter_ray_ok: finite origin, every component of d finite, nonzero and
+// within [2^-300, 2^300] (so no quotient is NaN or infinite), box and origin
+// coordinates at most 2^300, 2^-900 <= tmin < tmax.  Rays outside them take
+// the division form for every node.
 constexpr double FILTER_EPS = 0x1.0p-50;
 
-__device__ __forceinline__ bool box_hit_filtered(const DNode& n, V3 o, V3 d, V3 inv, double tmin, double tmax) {
-    double lo, hi;
-    box_fold((n.bmin[0] - o.x) * inv.x, (n.bmax[0] - o.x) * inv.x, (n.bmin[1] - o.y) * inv.y, (n.bmax[1] - o.y) * inv.y,
-             (n.bmin[2] - o.z) * inv.z, (n.bmax[2] - o.z) * inv.z, tmin, tmax, lo, hi);
-    if (lo * (1.0 + FILTER_EPS) < hi * (1.0 - FILTER_EPS)) return true;
-    if (lo * (1.0 - FILTER_EPS) >= hi * (1.0 + FILTER_EPS)) return false;
-    return box_hit_exact_slow(n, o, d, tmin, tmax);
+struct FilterBounds {   // tmin, tmax widened / narrowed by the margin
+    double tmin_lo, tmin_hi, tmax_lo, tmax_hi;
+};
+__device__ __forceinline__ void filter_set_tmin(FilterBounds& f, double tmin) {
+    f.tmin_lo = tmin * (1.0 - FILTER_EPS);
+    f.tmin_hi = tmin * (1.0 + FILTER_EPS);
+}
+__device__ __forceinline__ void filter_set_tmax(FilterBounds& f, double tmax) {
+    f.tmax_lo = tmax * (1.0 - FILTER_EPS);
+    f.tmax_hi = tmax * (1.0 + FILTER_EPS);
+}
+// 1 = hit for certain, 0 = miss for certain, -1 = undecided
+__device__ __forceinline__ int box_hit_filtered(const double bmin[3], const double bmax[3], V3 o, V3 inv, const FilterBounds& f) {
+    double t0x = (bmin[0] - o.x) * inv.x, t1x = (bmax[0] - o.x) * inv.x;
+    double t0y = (bmin[1] - o.y) * inv.y, t1y = (bmax[1] - o.y) * inv.y;
+    double t0z = (bmin[2] - o.z) * inv.z, t1z = (bmax[2] - o.z) * inv.z;
+    double lo = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmin(t0z, t1z));
+    double hi = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmax(t0z, t1z));
+    double diff = hi - lo;
+    double margin = FILTER_EPS * (fabs(hi) + fabs(lo));
+    bool hit = hi > f.tmin_hi && lo < f.tmax_lo && diff > margin;
+    bool miss = hi < f.tmin_lo || lo > f.tmax_hi || -diff > margin;
+    return hit ? 1 : (miss ? 0 : -1);
 }
 
 __device__ __forceinline__ bool filter_comp_ok(double d) {
     double a = fabs(d);
-    return d == 0.0 || (a >= 0x1.0p-300 && a <= 0x1.0p300);
+    return a >= 0x1.0p-300 && a <= 0x1.0p300;
 }
-__device__ __forceinline__ bool filter_ray_ok(V3 o, V3 d, double tmin) {
+__device__ __forceinline__ bool filter_ray_ok(V3 o, V3 d, double tmin, double tmax) {
     return filter_comp_ok(d.x) && filter_comp_ok(d.y) && filter_comp_ok(d.z) && fabs(o.x) <= 0x1.0p300 &&
-           fabs(o.y) <= 0x1.0p300 && fabs(o.z) <= 0x1.0p300 && tmin >= 0x1.0p-900;
+           fabs(o.y) <= 0x1.0p300 && fabs(o.z) <= 0x1.0p300 && tmin >= 0x1.0p-900 && tmin < tmax;
 }
 
 // ---------------------------------------------------------------- primitive tests

@@ -4,21 +4,19 @@
 
 namespace rtx {
 
-void launch_generate(const DCamera& cam, const DPool& pool, const uint32_t* free_queue, const uint32_t* n_free, uint32_t* queue_out,
-                     uint32_t* count_out, uint64_t max_count, DRenderCtl* ctl, uint64_t seed, uint32_t spp_begin,
-                     uint32_t max_blocks, hipStream_t s);
-void launch_iota(uint32_t* q, uint32_t n, hipStream_t s);
+void launch_generate(const DCamera& cam, const DState& st, uint32_t capacity, DRenderCtl* ctl, uint32_t parity, uint64_t seed,
+                     uint32_t spp_begin, uint32_t max_blocks, hipStream_t s);
 void launch_primary_rays(const DCamera& cam, uint64_t seed, uint32_t sample, uint32_t npix, double* org, double* dir,
                          uint32_t max_blocks, hipStream_t s);
-void launch_traverse(const DScene& sc, const DPool& pool, const uint32_t* queue, const uint32_t* count_ptr, uint32_t* zero_a,
-                     uint32_t* zero_b, uint64_t max_count, double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool exact,
+void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, const uint32_t* count_ptr, uint32_t* next_ray,
+                     uint64_t max_count, double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool exact,
                      uint32_t max_blocks, hipStream_t s);
-void launch_shade(const DScene& sc, const DCamera& cam, const DPool& pool, const uint32_t* queue_in, const uint32_t* count_in,
-                  uint32_t* queue_out, uint32_t* count_out, uint32_t* free_queue, uint32_t* n_free, uint64_t max_count,
-                  uint64_t seed, double* accum, uint32_t max_blocks, hipStream_t s);
+void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const uint32_t* count_in,
+                  const DState& nxt, uint32_t* count_out, uint64_t max_count, uint64_t seed, double* accum, uint32_t max_blocks,
+                  hipStream_t s);
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s);
 void launch_quantize(const double* in, uint64_t n, uint8_t* out, hipStream_t s);
-void launch_rays_to_pool(const double* org, const double* dir, uint64_t n, const DPool& pool, hipStream_t s);
+void launch_rays_to_state(const double* org, const double* dir, uint64_t n, const DState& st, hipStream_t s);
 void launch_user_ids(const DPrimInfo* prims, uint32_t* ids, uint64_t n, hipStream_t s);
 void launch_selftest_math(int op, const double* a, const double* b, uint64_t n, double* out, hipStream_t s);
 void launch_selftest_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, double* out, hipStream_t s);

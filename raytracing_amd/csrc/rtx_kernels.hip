@@ -1,12 +1,14 @@
 // rtx_kernels.hip -- gfx950 kernels of the wavefront path tracer.
 //
-//   k_generate      first fill of the path pool (sample_square + get_ray)
-//   k_traverse      closest hit over the threaded pre-order BVH  (BVH::hit)
-//   k_shade         complete the hit, emitted + scatter, accumulate finished
-//                   paths, restart the slot on the next (pixel, sample), and
-//                   compact the live slots into the next queue (64-wide
-//                   ballot + prefix count, one atomic per wave)
-//   k_scale / k_quantize   output stage
+// One round of the render loop is three launches on one stream:
+//   k_generate   start new paths (sample_square + get_ray) behind the
+//                survivors of the previous round, filling the state buffer
+//   k_traverse   closest hit of every live ray over the threaded pre-order
+//                BVH (BVH::hit); persistent waves that refill idle lanes
+//   k_shade      complete the hit, emitted + scatter, accumulate finished
+//                paths, and write the surviving paths densely into the other
+//                state buffer (64-wide ballot + prefix count, one atomic per wave)
+// k_scale / k_quantize are the output stage.
 //
 // Citations "file:line" are into the reference repository.
 #include "rtx_device.h"
@@ -17,10 +19,12 @@ namespace rtx {
 constexpr int BLOCK = 256;
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+__device__ __forceinline__ uint32_t rank_below(unsigned long long mask, uint32_t lane) {
+    return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
 
 // ---------------------------------------------------------------- primary rays
-// sample_square + get_ray, src/camera.rs:164-182.  `g` is the linear path
-// index: pixel = g % (W*H), sample = spp_begin + g / (W*H).
+// sample_square + get_ray, src/camera.rs:164-182.
 __device__ __forceinline__ void start_path(const DCamera& cam, uint64_t seed, uint32_t pixel, uint32_t sample,
                                            V3& origin, V3& direction, uint32_t& draw) {
     PathRng rng(seed, pixel, sample, 0u);
@@ -40,64 +44,58 @@ __device__ __forceinline__ void start_path(const DCamera& cam, uint64_t seed, ui
     draw = rng.draw;
 }
 
-__device__ __forceinline__ void store_new_path(const DPool& pool, uint32_t slot, const DCamera& cam, uint64_t seed,
-                                               uint32_t spp_begin, unsigned long long g) {
-    unsigned long long npix = (unsigned long long)cam.image_width * cam.image_height;
-    uint32_t sample_off = (uint32_t)(g / npix);
-    uint32_t pixel = (uint32_t)(g - (unsigned long long)sample_off * npix);
-    uint32_t sample = spp_begin + sample_off;
-    V3 o, d;
-    uint32_t draw;
-    start_path(cam, seed, pixel, sample, o, d, draw);
-    pool.ox[slot] = o.x; pool.oy[slot] = o.y; pool.oz[slot] = o.z;
-    pool.dx[slot] = d.x; pool.dy[slot] = d.y; pool.dz[slot] = d.z;
-    pool.bx[slot] = 1.0; pool.by[slot] = 1.0; pool.bz[slot] = 1.0;
-    pool.pixel[slot] = pixel;
-    pool.sample[slot] = sample;
-    pool.draw[slot] = draw;
-    pool.depth[slot] = 0u;
+// Path g of a render call is sample (spp_begin + g / npix) of pixel g % npix,
+// so consecutive lanes start neighbouring pixels of one sample index.
+__device__ __forceinline__ void split_path_index(unsigned long long g, unsigned long long npix, uint32_t& pixel, uint32_t& sample_off) {
+    unsigned long long q;
+    if (g < (1ull << 52)) {
+        // one f64 division instead of a software 64-bit one; exact in f64, the
+        // rounded quotient is off by at most one
+        q = (unsigned long long)((double)g / (double)npix);
+        if (q * npix > g) --q;
+        else if ((q + 1) * npix <= g) ++q;
+    } else {
+        q = g / npix;
+    }
+    sample_off = (uint32_t)q;
+    pixel = (uint32_t)(g - q * npix);
 }
 
-// Starts new paths in the slots the shade kernel has freed (or, on the first
-// round, in every slot): slot free_queue[i] gets the next unstarted
-// (pixel, sample) pair and is appended to the live queue.  One atomic per
-// wave on the path counter and one on the queue length.
-__global__ __launch_bounds__(BLOCK) void k_generate(DCamera cam, DPool pool, const uint32_t* free_queue, const uint32_t* n_free_ptr,
-                                                    uint32_t* queue_out, uint32_t* count_out, DRenderCtl* ctl, uint64_t seed,
-                                                    uint32_t spp_begin) {
-    const uint32_t n_free = *n_free_ptr;
-    const uint32_t lane = lane_id();
-    const uint32_t stride = gridDim.x * BLOCK;
-    const uint32_t rounds = (n_free + stride - 1) / stride;   // wave-uniform bound: every lane reaches the ballots
-    const unsigned long long total = ctl->total_paths;
-    for (uint32_t r = 0; r < rounds; ++r) {
-        uint32_t i = r * stride + blockIdx.x * BLOCK + threadIdx.x;
-        bool want = i < n_free;
-        unsigned long long wmask = __ballot(want);
-        if (!wmask) continue;
-        uint32_t leader = __ffsll((long long)wmask) - 1;
-        unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(&ctl->next_path, (unsigned long long)__popcll(wmask));
-        base = __shfl(base, leader);
-        unsigned long long g = base + __popcll(wmask & ((1ull << lane) - 1ull));
-        bool start = want && g < total;
-        uint32_t slot = 0;
-        if (start) {
-            slot = free_queue[i];
-            store_new_path(pool, slot, cam, seed, spp_begin, g);
-        }
-        unsigned long long smask = __ballot(start);
-        if (smask) {
-            uint32_t sl = __ffsll((long long)smask) - 1;
-            uint32_t qbase = 0;
-            if (lane == sl) qbase = atomicAdd(count_out, (uint32_t)__popcll(smask));
-            qbase = __shfl(qbase, sl);
-            if (start) queue_out[qbase + __popcll(smask & ((1ull << lane) - 1ull))] = slot;
-        }
+// Appends new paths behind the survivors in state buffer `st` until the
+// buffer is full or every path of the call has been started, and publishes
+// the round's ray count.  Thread 0 also resets the counters that the
+// following traverse and shade kernels bump.
+__global__ __launch_bounds__(BLOCK) void k_generate(DCamera cam, DState st, uint32_t capacity, DRenderCtl* ctl, uint32_t parity,
+                                                    uint64_t seed, uint32_t spp_begin) {
+    const uint32_t n_surv = ctl->count_surv[parity];
+    const unsigned long long next = ctl->next_path[parity];
+    const unsigned long long left = ctl->total_paths - next;
+    const uint32_t room = capacity - n_surv;
+    const uint32_t n_new = left < room ? (uint32_t)left : room;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->next_path[parity ^ 1u] = next + n_new;
+        ctl->count_live = n_surv + n_new;
+        ctl->rays += n_surv + n_new;
+        ctl->next_ray = 0u;
+        ctl->count_surv[parity ^ 1u] = 0u;
     }
-}
-__global__ __launch_bounds__(BLOCK) void k_iota(uint32_t* q, uint32_t n) {
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) q[i] = i;
+    const unsigned long long npix = (unsigned long long)cam.image_width * cam.image_height;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_new; i += gridDim.x * BLOCK) {
+        uint32_t pixel, sample_off;
+        split_path_index(next + i, npix, pixel, sample_off);
+        const uint32_t sample = spp_begin + sample_off;
+        V3 o, d;
+        uint32_t draw;
+        start_path(cam, seed, pixel, sample, o, d, draw);
+        const uint32_t k = n_surv + i;
+        st.ox[k] = o.x; st.oy[k] = o.y; st.oz[k] = o.z;
+        st.dx[k] = d.x; st.dy[k] = d.y; st.dz[k] = d.z;
+        st.bx[k] = 1.0; st.by[k] = 1.0; st.bz[k] = 1.0;
+        st.pixel[k] = pixel;
+        st.sample[k] = sample;
+        st.draw[k] = draw;
+        st.depth[k] = 0u;
+    }
 }
 
 // Primary rays only, for the parity API (rays laid out [n][3]).
@@ -115,77 +113,136 @@ __global__ __launch_bounds__(BLOCK) void k_primary_rays(DCamera cam, uint64_t se
 // ---------------------------------------------------------------- closest hit
 // impl Hittable for BVH::hit, src/bvh/mod.rs:134-174.
 //
-// The reference pops node indices from an explicit stack, pushing the right
-// child and then the left child (i+1) of every internal node whose box is
-// hit.  Because the children are always visited left first, the node popped
-// after a subtree is finished or culled depends only on where that subtree
-// ends in the pre-order array.  That successor is stored per node (`miss`),
-// so the traversal needs no stack: box missed -> miss; internal hit -> i+1;
-// leaf -> test the surface, then miss.  The visit order, the shrinking
-// interval and the tie rule (`hit.t > nearest.t` keeps the old hit, :159-167)
-// are exactly the reference's.
+// Order of visits.  The reference pops node indices from an explicit stack,
+// pushing the right child and then the left child (i+1) of every internal
+// node whose box is hit.  Because children are always visited left first,
+// the node popped after a subtree is finished or culled depends only on where
+// that subtree ends in the pre-order array.  That successor is stored per
+// node (`miss`), so the walk needs no stack: box missed -> miss; internal hit
+// -> i+1; leaf -> test the surface, then miss.  The visit order, the
+// shrinking interval and the tie rule (`hit.t > nearest.t` keeps the old hit,
+// :159-167) are exactly the reference's.
+//
+// Shape of the kernel.  Waves are persistent: a lane that has finished its
+// ray takes the next one from a global counter (one atomic per wave), so
+// short rays do not leave lanes idle while long ones finish.  Each wave
+// alternates two phases: all lanes walk nodes until they stand on a leaf
+// whose box is hit (or run out of tree), then the lanes that found one test
+// their surface together.  A ray's own sequence of box and surface tests is
+// unchanged by this; only when the wave executes them is.
 template <bool COUNT, bool EXACT>
-__device__ __forceinline__ void closest_hit(const DScene& sc, V3 o, V3 d, double tmin, double tmax, uint32_t& best_prim,
-                                            double& best_t, uint32_t& n_nodes, uint32_t& n_sph, uint32_t& n_pln) {
-    best_prim = NONE;
-    best_t = tmax;
-    const bool filtered = !EXACT && sc.filter_ok && filter_ray_ok(o, d, tmin);
-    V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-    uint32_t node = 0;
-    const uint32_t end = sc.n_nodes;
-    while (node < end) {
-        const DNode& nd = sc.nodes[node];
-        if (COUNT) ++n_nodes;
-        bool hit = filtered ? box_hit_filtered(nd, o, d, inv, tmin, tmax) : box_hit_exact(nd, o, d, tmin, tmax);
-        if (!hit) {
-            node = nd.miss;
-            continue;
-        }
-        uint32_t prim = nd.prim;
-        if (prim == NONE) {
-            node = node + 1;
-            continue;
-        }
-        double t;
-        bool ph;
-        if (nd.kind == 0u) {
-            if (COUNT) ++n_sph;
-            ph = sphere_t(sc.spheres[nd.slot], o, d, tmin, tmax, t);
-        } else {
-            if (COUNT) ++n_pln;
-            double al, be;
-            ph = planar_t(sc.planars[nd.slot], nd.kind, o, d, tmin, tmax, t, al, be);
-        }
-        // `if let Some(nearest) = acc && hit.t > nearest.t { keep } else { replace }`
-        if (ph && !(best_prim != NONE && t > best_t)) {
-            best_prim = prim;
-            best_t = t;
-            tmax = t;   // shrunken_ray_t.max = hit.t
-        }
-        node = nd.miss;
-    }
-}
-
-template <bool COUNT, bool EXACT>
-__global__ __launch_bounds__(BLOCK) void k_traverse(DScene sc, DPool pool, const uint32_t* queue, const uint32_t* count_ptr,
-                                                    uint32_t* zero_a, uint32_t* zero_b, double tmin, double tmax, DRenderCtl* ctl) {
+__global__ __launch_bounds__(BLOCK) void k_traverse(DScene sc, DState rays, DHits hits, const uint32_t* count_ptr,
+                                                    uint32_t* next_ray, double tmin, double tmax0, DRenderCtl* ctl) {
+    constexpr uint32_t REFILL_AT = 16;   // fetch new rays once this many lanes are idle
     const uint32_t count = *count_ptr;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // lengths of the queues the following shade / generate kernels append to
-        if (zero_a) *zero_a = 0u;
-        if (zero_b) *zero_b = 0u;
-        if (ctl) atomicAdd(&ctl->rays, (unsigned long long)count);
-    }
+    const uint32_t lane = lane_id();
+    const uint32_t end = sc.n_nodes;
+    const bool scene_filter = !EXACT && sc.filter_ok != 0u;
+
+    uint32_t idx = NONE;   // ray of this lane, NONE = idle
+    V3 o = v3(0, 0, 0), d = v3(1, 1, 1), inv = v3(1, 1, 1);
+    double tmax = tmax0, best_t = tmax0;
+    uint32_t best_prim = NONE, node = 0;
+    bool filtered = false;
+    FilterBounds fb;
+    filter_set_tmin(fb, tmin);
+    filter_set_tmax(fb, tmax0);
     uint32_t c_nodes = 0, c_sph = 0, c_pln = 0;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
-        uint32_t slot = queue ? queue[i] : i;
-        V3 o = v3(pool.ox[slot], pool.oy[slot], pool.oz[slot]);
-        V3 d = v3(pool.dx[slot], pool.dy[slot], pool.dz[slot]);
-        uint32_t prim;
-        double t;
-        closest_hit<COUNT, EXACT>(sc, o, d, tmin, tmax, prim, t, c_nodes, c_sph, c_pln);
-        pool.hit_prim[slot] = prim;
-        pool.hit_t[slot] = t;
+    bool more = true;      // the counter has not run past `count` yet (wave-uniform)
+
+    for (;;) {
+        // ---- refill
+        const unsigned long long idle = __ballot(idx == NONE);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (more && (n_idle >= REFILL_AT)) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(next_ray, n_idle);
+            base = __shfl(base, leader);
+            if (base + n_idle >= count) more = false;
+            if (idx == NONE) {
+                const uint32_t mine = base + rank_below(idle, lane);
+                if (mine < count) {
+                    idx = mine;
+                    o = v3(rays.ox[mine], rays.oy[mine], rays.oz[mine]);
+                    d = v3(rays.dx[mine], rays.dy[mine], rays.dz[mine]);
+                    tmax = tmax0;
+                    best_t = tmax0;
+                    best_prim = NONE;
+                    node = 0;
+                    filtered = scene_filter && filter_ray_ok(o, d, tmin, tmax0);
+                    inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                    filter_set_tmax(fb, tmax0);
+                }
+            }
+        }
+        if (__ballot(idx != NONE) == 0ull) {
+            if (!more) break;
+            continue;   // fewer than REFILL_AT lanes were idle a moment ago and all have retired since
+        }
+
+        // ---- phase 1: walk to the next leaf whose box is hit
+        bool searching = idx != NONE && node < end;
+        bool pending = false;
+        uint32_t leaf_kind = 0, leaf_slot = 0, leaf_prim = NONE;
+        while (__ballot(searching) != 0ull) {
+            if (searching) {
+                const DNode& nd = sc.nodes[node];
+                if (COUNT) ++c_nodes;
+                bool hit;
+                if (filtered) {
+                    int r = box_hit_filtered(nd.bmin, nd.bmax, o, inv, fb);
+                    hit = r > 0;
+                    if (r < 0) hit = box_hit_exact_slow(nd.bmin, nd.bmax, o, d, tmin, tmax);
+                } else if (EXACT) {
+                    hit = box_hit_exact(nd.bmin, nd.bmax, o, d, tmin, tmax);
+                } else {
+                    hit = box_hit_exact_slow(nd.bmin, nd.bmax, o, d, tmin, tmax);
+                }
+                const uint32_t prim = nd.prim;
+                if (!hit) {
+                    node = nd.miss;
+                } else if (prim == NONE) {
+                    node = node + 1u;
+                } else {
+                    pending = true;
+                    leaf_prim = prim;
+                    leaf_kind = nd.kind;
+                    leaf_slot = nd.slot;
+                    node = nd.miss;   // a leaf's successor is the next node
+                    searching = false;
+                }
+                if (node >= end) searching = false;
+            }
+        }
+
+        // ---- phase 2: surface tests of the lanes standing on a leaf
+        if (pending) {
+            double t;
+            bool ph;
+            if (leaf_kind == 0u) {
+                if (COUNT) ++c_sph;
+                ph = sphere_t(sc.spheres[leaf_slot], o, d, tmin, tmax, t);
+            } else {
+                if (COUNT) ++c_pln;
+                double al, be;
+                ph = planar_t(sc.planars[leaf_slot], leaf_kind, o, d, tmin, tmax, t, al, be);
+            }
+            // `if let Some(nearest) = acc && hit.t > nearest.t { keep } else { replace }`
+            if (ph && !(best_prim != NONE && t > best_t)) {
+                best_prim = leaf_prim;
+                best_t = t;
+                tmax = t;   // shrunken_ray_t.max = hit.t
+                filter_set_tmax(fb, t);
+            }
+        }
+
+        // ---- retire rays that have run out of tree
+        if (idx != NONE && node >= end) {
+            hits.prim[idx] = best_prim;
+            hits.t[idx] = best_t;
+            idx = NONE;
+        }
     }
     if (COUNT && ctl) {
         atomicAdd(&ctl->node_visits, (unsigned long long)c_nodes);
@@ -212,41 +269,40 @@ __device__ __forceinline__ double reflectance(double cos_theta, double refractio
 // The reference nests `emitted + ray_color(..) * attenuation`; with emission
 // only on surfaces that do not scatter this is the same product of
 // attenuations, associated from the other end.
-__global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DPool pool, const uint32_t* queue_in,
-                                                 const uint32_t* count_in, uint32_t* queue_out, uint32_t* count_out,
-                                                 uint32_t* free_queue, uint32_t* n_free, uint64_t seed, double* accum) {
+__global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DState cur, DHits hits, const uint32_t* count_in,
+                                                 DState nxt, uint32_t* count_out, uint64_t seed, double* accum) {
     const uint32_t count = *count_in;
     const uint32_t lane = lane_id();
     const uint32_t stride = gridDim.x * BLOCK;
-    // the loop bound is wave-uniform so every lane reaches the ballots
+    // the loop bound is wave-uniform so every lane reaches the ballot
     const uint32_t rounds = (count + stride - 1) / stride;
     for (uint32_t r = 0; r < rounds; ++r) {
-        uint32_t i = r * stride + blockIdx.x * BLOCK + threadIdx.x;
-        bool active = i < count;
-        bool alive = false;     // slot goes into the next queue
-        uint32_t slot = 0;
-        if (active) {
-            slot = queue_in[i];
-            uint32_t prim = pool.hit_prim[slot];
-            V3 beta = v3(pool.bx[slot], pool.by[slot], pool.bz[slot]);
-            uint32_t pixel = pool.pixel[slot];
+        const uint32_t i = r * stride + blockIdx.x * BLOCK + threadIdx.x;
+        bool alive = false;
+        V3 p = v3(0, 0, 0), nd = v3(0, 0, 0), beta = v3(0, 0, 0);
+        uint32_t pixel = 0, sample = 0, draw = 0, depth = 0;
+        if (i < count) {
+            const uint32_t prim = hits.prim[i];
+            beta = v3(cur.bx[i], cur.by[i], cur.bz[i]);
+            pixel = cur.pixel[i];
             V3 radiance = v3(0.0, 0.0, 0.0);
             bool add = false;
             if (prim == NONE) {
                 radiance = beta * ld3(cam.background);   // camera.rs:207
                 add = true;
             } else {
-                V3 o = v3(pool.ox[slot], pool.oy[slot], pool.oz[slot]);
-                V3 d = v3(pool.dx[slot], pool.dy[slot], pool.dz[slot]);
-                double t = pool.hit_t[slot];
-                DPrimInfo pi = sc.prims[prim];
-                DMaterial m = sc.materials[pi.material];
+                const V3 o = v3(cur.ox[i], cur.oy[i], cur.oz[i]);
+                const V3 d = v3(cur.dx[i], cur.dy[i], cur.dz[i]);
+                const double t = hits.t[i];
+                sample = cur.sample[i];
+                const DPrimInfo pi = sc.prims[prim];
+                const DMaterial m = sc.materials[pi.material];
                 // complete the Hit for the winning surface (geometry.rs:232-249, 280-288)
-                V3 p = o + d * t;
+                p = o + d * t;
                 V3 outward;
                 double alpha = 0.0, beta_uv = 0.0;
                 if (pi.kind == 0u) {
-                    DSphere s = sc.spheres[pi.slot];
+                    const DSphere s = sc.spheres[pi.slot];
                     outward = (p - v3(s.c[0], s.c[1], s.c[2])) / s.r;
                     if (m.kind == 4u) {   // u,v only feed UVGradient (geometry.rs:236-240)
                         const double PI = 3.14159265358979323846264338327950288;
@@ -265,8 +321,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DPool p
                         beta_uv = dot(w, cross(ld3(g.u), qp));
                     }
                 }
-                bool front_face = dot(d, outward) < 0.0;           // geometry.rs:135-145
-                V3 n = front_face ? outward : -outward;
+                const bool front_face = dot(d, outward) < 0.0;           // geometry.rs:135-145
+                const V3 n = front_face ? outward : -outward;
 
                 // Material::emitted, material.rs:35-54
                 if (m.kind == 3u) {
@@ -280,14 +336,14 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DPool p
                 }
 
                 // Material::scatter, material.rs:20-33
-                PathRng rng(seed, pixel, pool.sample[slot], pool.draw[slot]);
+                PathRng rng(seed, pixel, sample, cur.draw[i]);
                 rng.begin_event();
                 bool scattered = false;
-                V3 nd = v3(0.0, 0.0, 0.0), att = v3(1.0, 1.0, 1.0);
+                V3 att = v3(1.0, 1.0, 1.0);
                 if (m.kind <= 1u) {
                     // Lambertian and Metal both start with Vector3::random_unit()
                     // (material.rs:62, :86); one shared rejection loop for the wave
-                    V3 ru = random_unit(rng);
+                    const V3 ru = random_unit(rng);
                     att = ld3(m.rgb);
                     if (m.kind == 0u) {        // lambertian, material.rs:61-73
                         V3 direction = n + ru;
@@ -311,14 +367,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DPool p
                     nd = refl ? reflect(r_in, n) : refract(r_in, n, eta);
                     scattered = true;
                 }
-                uint32_t depth = pool.depth[slot] + 1u;
+                depth = cur.depth[i] + 1u;
                 if (scattered && depth < cam.max_depth) {
                     beta = beta * att;
-                    pool.ox[slot] = p.x; pool.oy[slot] = p.y; pool.oz[slot] = p.z;
-                    pool.dx[slot] = nd.x; pool.dy[slot] = nd.y; pool.dz[slot] = nd.z;
-                    pool.bx[slot] = beta.x; pool.by[slot] = beta.y; pool.bz[slot] = beta.z;
-                    pool.draw[slot] = rng.draw;
-                    pool.depth[slot] = depth;
+                    draw = rng.draw;
                     alive = true;
                 }
             }
@@ -329,25 +381,23 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DPool p
                 if (radiance.z != 0.0) unsafeAtomicAdd(px + 2, radiance.z);
             }
         }
-        // compaction: live slots into the next queue, finished slots into the
-        // free queue (64-wide ballot + prefix popcount, one atomic per wave and queue)
-        const bool finished = active && !alive;
-        unsigned long long amask = __ballot(alive);
-        unsigned long long fmask = __ballot(finished);
-        const unsigned long long below = (1ull << lane) - 1ull;
+        // compaction: surviving paths go densely into the other state buffer
+        const unsigned long long amask = __ballot(alive);
         if (amask) {
-            uint32_t leader = __ffsll((long long)amask) - 1;
+            const uint32_t leader = (uint32_t)__ffsll((long long)amask) - 1u;
             uint32_t base = 0;
             if (lane == leader) base = atomicAdd(count_out, (uint32_t)__popcll(amask));
             base = __shfl(base, leader);
-            if (alive) queue_out[base + __popcll(amask & below)] = slot;
-        }
-        if (fmask) {
-            uint32_t leader = __ffsll((long long)fmask) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(n_free, (uint32_t)__popcll(fmask));
-            base = __shfl(base, leader);
-            if (finished) free_queue[base + __popcll(fmask & below)] = slot;
+            if (alive) {
+                const uint32_t k = base + rank_below(amask, lane);
+                nxt.ox[k] = p.x; nxt.oy[k] = p.y; nxt.oz[k] = p.z;
+                nxt.dx[k] = nd.x; nxt.dy[k] = nd.y; nxt.dz[k] = nd.z;
+                nxt.bx[k] = beta.x; nxt.by[k] = beta.y; nxt.bz[k] = beta.z;
+                nxt.pixel[k] = pixel;
+                nxt.sample[k] = sample;
+                nxt.draw[k] = draw;
+                nxt.depth[k] = depth;
+            }
         }
     }
 }
@@ -366,11 +416,11 @@ __global__ __launch_bounds__(BLOCK) void k_quantize(const double* in, uint64_t n
     }
 }
 
-// transposes rays [n][3] (API layout) into the pool's per-component arrays
-__global__ __launch_bounds__(BLOCK) void k_rays_to_pool(const double* org, const double* dir, uint64_t n, DPool pool) {
+// transposes rays [n][3] (API layout) into per-component arrays
+__global__ __launch_bounds__(BLOCK) void k_rays_to_state(const double* org, const double* dir, uint64_t n, DState st) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
-        pool.ox[i] = org[3 * i + 0]; pool.oy[i] = org[3 * i + 1]; pool.oz[i] = org[3 * i + 2];
-        pool.dx[i] = dir[3 * i + 0]; pool.dy[i] = dir[3 * i + 1]; pool.dz[i] = dir[3 * i + 2];
+        st.ox[i] = org[3 * i + 0]; st.oy[i] = org[3 * i + 1]; st.oz[i] = org[3 * i + 2];
+        st.dx[i] = dir[3 * i + 0]; st.dy[i] = dir[3 * i + 1]; st.dz[i] = dir[3 * i + 2];
     }
 }
 __global__ __launch_bounds__(BLOCK) void k_user_ids(const DPrimInfo* prims, uint32_t* ids, uint64_t n) {
@@ -403,36 +453,31 @@ static inline uint32_t grid_for(uint64_t n, uint32_t max_blocks) {
     return (uint32_t)b;
 }
 
-void launch_generate(const DCamera& cam, const DPool& pool, const uint32_t* free_queue, const uint32_t* n_free, uint32_t* queue_out,
-                     uint32_t* count_out, uint64_t max_count, DRenderCtl* ctl, uint64_t seed, uint32_t spp_begin,
-                     uint32_t max_blocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(max_count, max_blocks)), dim3(BLOCK), 0, s, cam, pool, free_queue, n_free, queue_out,
-                       count_out, ctl, seed, spp_begin);
-}
-void launch_iota(uint32_t* q, uint32_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, q, n);
+void launch_generate(const DCamera& cam, const DState& st, uint32_t capacity, DRenderCtl* ctl, uint32_t parity, uint64_t seed,
+                     uint32_t spp_begin, uint32_t max_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(capacity, max_blocks)), dim3(BLOCK), 0, s, cam, st, capacity, ctl, parity, seed, spp_begin);
 }
 void launch_primary_rays(const DCamera& cam, uint64_t seed, uint32_t sample, uint32_t npix, double* org, double* dir,
                          uint32_t max_blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_primary_rays, dim3(grid_for(npix, max_blocks)), dim3(BLOCK), 0, s, cam, seed, sample, npix, org, dir);
 }
-void launch_traverse(const DScene& sc, const DPool& pool, const uint32_t* queue, const uint32_t* count_ptr, uint32_t* zero_a,
-                     uint32_t* zero_b, uint64_t max_count, double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool exact,
+void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, const uint32_t* count_ptr, uint32_t* next_ray,
+                     uint64_t max_count, double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool exact,
                      uint32_t max_blocks, hipStream_t s) {
     dim3 g(grid_for(max_count, max_blocks)), b(BLOCK);
     if (count_work) {
-        if (exact) hipLaunchKernelGGL((k_traverse<true, true>), g, b, 0, s, sc, pool, queue, count_ptr, zero_a, zero_b, tmin, tmax, ctl);
-        else hipLaunchKernelGGL((k_traverse<true, false>), g, b, 0, s, sc, pool, queue, count_ptr, zero_a, zero_b, tmin, tmax, ctl);
+        if (exact) hipLaunchKernelGGL((k_traverse<true, true>), g, b, 0, s, sc, rays, hits, count_ptr, next_ray, tmin, tmax, ctl);
+        else hipLaunchKernelGGL((k_traverse<true, false>), g, b, 0, s, sc, rays, hits, count_ptr, next_ray, tmin, tmax, ctl);
     } else {
-        if (exact) hipLaunchKernelGGL((k_traverse<false, true>), g, b, 0, s, sc, pool, queue, count_ptr, zero_a, zero_b, tmin, tmax, ctl);
-        else hipLaunchKernelGGL((k_traverse<false, false>), g, b, 0, s, sc, pool, queue, count_ptr, zero_a, zero_b, tmin, tmax, ctl);
+        if (exact) hipLaunchKernelGGL((k_traverse<false, true>), g, b, 0, s, sc, rays, hits, count_ptr, next_ray, tmin, tmax, ctl);
+        else hipLaunchKernelGGL((k_traverse<false, false>), g, b, 0, s, sc, rays, hits, count_ptr, next_ray, tmin, tmax, ctl);
     }
 }
-void launch_shade(const DScene& sc, const DCamera& cam, const DPool& pool, const uint32_t* queue_in, const uint32_t* count_in,
-                  uint32_t* queue_out, uint32_t* count_out, uint32_t* free_queue, uint32_t* n_free, uint64_t max_count,
-                  uint64_t seed, double* accum, uint32_t max_blocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(max_count, max_blocks)), dim3(BLOCK), 0, s, sc, cam, pool, queue_in, count_in,
-                       queue_out, count_out, free_queue, n_free, seed, accum);
+void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const uint32_t* count_in,
+                  const DState& nxt, uint32_t* count_out, uint64_t max_count, uint64_t seed, double* accum, uint32_t max_blocks,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(max_count, max_blocks)), dim3(BLOCK), 0, s, sc, cam, cur, hits, count_in, nxt, count_out,
+                       seed, accum);
 }
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_scale, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, in, n, scale, out);
@@ -440,8 +485,8 @@ void launch_scale(const double* in, uint64_t n, double scale, double* out, hipSt
 void launch_quantize(const double* in, uint64_t n, uint8_t* out, hipStream_t s) {
     hipLaunchKernelGGL(k_quantize, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, in, n, out);
 }
-void launch_rays_to_pool(const double* org, const double* dir, uint64_t n, const DPool& pool, hipStream_t s) {
-    hipLaunchKernelGGL(k_rays_to_pool, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, org, dir, n, pool);
+void launch_rays_to_state(const double* org, const double* dir, uint64_t n, const DState& st, hipStream_t s) {
+    hipLaunchKernelGGL(k_rays_to_state, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, org, dir, n, st);
 }
 void launch_user_ids(const DPrimInfo* prims, uint32_t* ids, uint64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_user_ids, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, prims, ids, n);
