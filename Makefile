@@ -3,7 +3,8 @@
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 # -ffp-contract=off: results are compared bit-for-bit with an unfused f64 reference.
-HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -munsafe-fp-atomics -Wall -Wno-unused-result
+EXTRA    ?=
+HIPFLAGS ?= $(EXTRA) -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -munsafe-fp-atomics -Wall -Wno-unused-result
 
 LIB  := raytracing_amd/librtx.so
 SRCS := raytracing_amd/csrc/rtx_kernels.hip raytracing_amd/csrc/rtx_api.cpp raytracing_amd/host/rtx_host.cpp

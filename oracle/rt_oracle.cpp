@@ -283,10 +283,16 @@ inline void philox4x32_10(const uint32_t c_in[4], const uint32_t k_in[2], uint32
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Uniform doubles of one path.  Stream = (seed, pixel index, sample index);
-// draw i is element (i & 1) of Philox block (i >> 1) with counter
-// (pixel, sample, block, 0) and key (seed_lo, seed_hi); a 64-bit word w maps
-// to (w >> 11) * 2^-53 in [0,1), the same mapping rand's StandardUniform uses.
+// Random numbers of one path.  Stream = (seed, pixel index, sample index):
+// block b is Philox4x32-10 with counter (pixel, sample, b, 0) and key
+// (seed_lo, seed_hi); it yields the 64-bit words w0 = out[1]:out[0] and
+// w1 = out[3]:out[2].
+//   * a uniform double takes one word, (w >> 11) * 2^-53 in [0,1), the same
+//     mapping rand's StandardUniform uses (draw i is word i & 1 of block i >> 1);
+//   * one trial of random_unit's rejection loop takes one whole block: three
+//     42-bit uniforms (top 42 bits of w0, top 42 bits of w1, low 22 bits of w0
+//     followed by the low 20 bits of w1).  rand's random_range uses 52 bits;
+//     42 keeps a trial to one block and is far below any visible granularity.
 struct PathRng {
     uint32_t key[2];
     uint32_t pixel, sample;
@@ -300,13 +306,17 @@ struct PathRng {
     }
     // every sampling event (camera sample, one scatter call) starts on a block boundary
     void begin_event() { draw = (draw + 1u) & ~1u; }
+    void block(uint32_t blk, uint64_t& w0, uint64_t& w1) const {
+        uint32_t c[4] = {pixel, sample, blk, 0u}, o[4];
+        philox4x32_10(c, key, o);
+        w0 = ((uint64_t)o[1] << 32) | o[0];
+        w1 = ((uint64_t)o[3] << 32) | o[2];
+    }
     double next() {
         uint32_t blk = draw >> 1;
         if (blk != cached_block) {
-            uint32_t c[4] = {pixel, sample, blk, 0u}, o[4];
-            philox4x32_10(c, key, o);
-            uint64_t w0 = ((uint64_t)o[1] << 32) | o[0];
-            uint64_t w1 = ((uint64_t)o[3] << 32) | o[2];
+            uint64_t w0, w1;
+            block(blk, w0, w1);
             cached[0] = (double)(w0 >> 11) * 0x1.0p-53;
             cached[1] = (double)(w1 >> 11) * 0x1.0p-53;
             cached_block = blk;
@@ -315,15 +325,23 @@ struct PathRng {
     }
     // rand::random_range(lo..hi) for f64: u * (hi - lo) + lo
     double range(double lo, double hi) { return next() * (hi - lo) + lo; }
+    void next3(double& a, double& b, double& c) {
+        begin_event();
+        uint64_t w0, w1;
+        block(draw >> 1, w0, w1);
+        draw += 2u;
+        a = (double)(w0 >> 22) * 0x1.0p-42;
+        b = (double)(w1 >> 22) * 0x1.0p-42;
+        c = (double)(((w0 & 0x3FFFFFull) << 20) | (w1 & 0xFFFFFull)) * 0x1.0p-42;
+    }
 };
 
 // vector.rs:59-81
 inline V3 random_unit(PathRng& rng) {
     for (;;) {
-        double x = rng.range(-1.0, 1.0);
-        double y = rng.range(-1.0, 1.0);
-        double z = rng.range(-1.0, 1.0);
-        V3 candidate = v3(x, y, z);
+        double a, b, c;
+        rng.next3(a, b, c);
+        V3 candidate = v3(a * 2.0 + -1.0, b * 2.0 + -1.0, c * 2.0 + -1.0);   // random_range(-1.0..1.0)
         double lensq = length_squared(candidate);
         if (1e-160 < lensq && lensq <= 1.0) return candidate / std::sqrt(lensq);
     }

@@ -284,7 +284,7 @@ int rtx_trace_closest(rtx_scene* sc, const double* org, const double* dir, uint6
     launch_rays_to_state(d_rays.p, d_rays.p + 3 * n, n, sc->state[0], s);
     const uint32_t max_blocks = sc->n_cus * env_u32("RTX_BLOCKS_PER_CU", 8);
     HIP_TRY(hipEventRecord(sc->ev0, s));
-    launch_traverse(sc->d, sc->state[0], sc->hits, &sc->ctl.p->count_live, &sc->ctl.p->next_ray, n, tmin, tmax, sc->ctl.p,
+    launch_traverse(sc->d, sc->state[0], sc->hits, &sc->ctl.p->count_live, n, tmin, tmax, sc->ctl.p,
                     (flags & RTX_FLAG_COUNT_WORK) != 0, (flags & RTX_FLAG_EXACT_DIVIDE) != 0, max_blocks, s);
     HIP_TRY(hipEventRecord(sc->ev1, s));
     launch_user_ids(sc->d.prims, sc->hits.prim, n, s);
@@ -406,7 +406,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         }
         launch_generate(dcam, sc->state[cur], slots, ctl, cur, seed, spp_begin, max_blocks, s);
         if (time_kernels) (void)hipEventRecord(e0, s);
-        launch_traverse(sc->d, sc->state[cur], sc->hits, &ctl->count_live, &ctl->next_ray, slots, 0.001, INFINITY, ctl,
+        launch_traverse(sc->d, sc->state[cur], sc->hits, &ctl->count_live, slots, 0.001, INFINITY, ctl,
                         count_work, exact, max_blocks, s);   // Interval(0.001, inf), camera.rs:194
         if (time_kernels) (void)hipEventRecord(e1, s);
         launch_shade(sc->d, dcam, sc->state[cur], sc->hits, &ctl->count_live, sc->state[nxt], &ctl->count_surv[nxt], slots, seed,

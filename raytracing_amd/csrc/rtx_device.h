@@ -20,7 +20,7 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 // the node the reference's explicit stack (src/bvh/mod.rs:135-156) would pop
 // next after this subtree is finished or culled.
 struct __attribute__((aligned(64))) DNode {
-    double bmin[3];
+    double bmin[3];   // the traverse kernel reads the record as 3 x double2 + 1 x uint4
     double bmax[3];
     uint32_t miss;   // next node when the box is missed or the leaf is done
     uint32_t prim;   // leaf: prim index; internal: NONE
@@ -134,27 +134,35 @@ __device__ __forceinline__ V3 refract(V3 r_in, V3 n, double eta) {              
 __device__ __forceinline__ V3 ld3(const double* p) { return v3(p[0], p[1], p[2]); }
 
 // ---------------------------------------------------------------- RNG
-// Philox4x32-10.  One block gives two uniform doubles.
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3").
+// The 32x32->64 products are written as one 64-bit multiply each so that a
+// single v_mad_u64_u32 yields both halves.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = hi1 ^ c1 ^ k0;
-        uint32_t n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Uniform doubles of one path: draw i is element (i & 1) of block (i >> 1),
-// counter (pixel, sample, block, 0), key = the 64-bit seed.  A 64-bit word w
-// maps to (w >> 11) * 2^-53.  Every sampling event (the camera sample, each
-// scatter call) starts on a block boundary, so `draw` is the only RNG state
-// a path carries between kernels.
+// Random numbers of one path.  Stream = (seed, pixel index, sample index):
+// block b is Philox4x32-10 with counter (pixel, sample, b, 0) and the 64-bit
+// seed as key; it yields the 64-bit words w0 = out[1]:out[0], w1 = out[3]:out[2].
+//   * a uniform double takes one word: (w >> 11) * 2^-53 (draw i is word
+//     i & 1 of block i >> 1);
+//   * one trial of the unit-vector rejection sampler takes one whole block:
+//     three 42-bit uniforms (top 42 bits of w0, top 42 bits of w1, and the
+//     low 22 bits of w0 followed by the low 20 bits of w1).
+// Every sampling event (the camera sample, each scatter call) starts on a
+// block boundary, so the draw index is the only RNG state a path carries
+// between kernels.
 struct PathRng {
     uint32_t k0, k1, pixel, sample, draw, cached_block;
     double cached[2];
@@ -179,15 +187,26 @@ struct PathRng {
         return r;
     }
     __device__ __forceinline__ double range(double lo, double hi) { return next() * (hi - lo) + lo; }
+    // three uniforms in [0,1) with 42-bit resolution from one block
+    __device__ __forceinline__ void next3(double& a, double& b, double& c) {
+        begin_event();
+        uint32_t o[4];
+        philox4x32_10(pixel, sample, draw >> 1, 0u, k0, k1, o);
+        draw += 2u;
+        const uint64_t w0 = ((uint64_t)o[1] << 32) | o[0];
+        const uint64_t w1 = ((uint64_t)o[3] << 32) | o[2];
+        a = (double)(w0 >> 22) * 0x1.0p-42;
+        b = (double)(w1 >> 22) * 0x1.0p-42;
+        c = (double)(((w0 & 0x3FFFFFull) << 20) | (w1 & 0xFFFFFull)) * 0x1.0p-42;
+    }
 };
 
-// src/vector.rs:59-81
+// src/vector.rs:59-81: rejection from the cube, one Philox block per trial
 __device__ __forceinline__ V3 random_unit(PathRng& rng) {
     for (;;) {
-        double x = rng.range(-1.0, 1.0);
-        double y = rng.range(-1.0, 1.0);
-        double z = rng.range(-1.0, 1.0);
-        V3 candidate = v3(x, y, z);
+        double a, b, c;
+        rng.next3(a, b, c);
+        V3 candidate = v3(a * 2.0 + -1.0, b * 2.0 + -1.0, c * 2.0 + -1.0);   // random_range(-1.0..1.0)
         double lensq = length_squared(candidate);
         if (1e-160 < lensq && lensq <= 1.0) return candidate / sqrt(lensq);
     }
@@ -223,7 +242,10 @@ __device__ __forceinline__ bool box_hit_exact(const double bmin[3], const double
 }
 // out-of-line copy for the filtered test's rare fallback, so the six
 // divisions stay out of the hot loop's instruction stream and registers
-__device__ __noinline__ bool box_hit_exact_slow(const double bmin[3], const double bmax[3], V3 o, V3 d, double tmin, double tmax) {
+// (box passed by value: pointer arguments would force the caller's copy into scratch memory)
+__device__ __noinline__ bool box_hit_exact_slow(double b0, double b1, double b2, double b3, double b4, double b5, V3 o, V3 d,
+                                                double tmin, double tmax) {
+    const double bmin[3] = {b0, b1, b2}, bmax[3] = {b3, b4, b5};
     return box_hit_exact(bmin, bmax, o, d, tmin, tmax);
 }
 

@@ -8,7 +8,7 @@ void launch_generate(const DCamera& cam, const DState& st, uint32_t capacity, DR
                      uint32_t spp_begin, uint32_t max_blocks, hipStream_t s);
 void launch_primary_rays(const DCamera& cam, uint64_t seed, uint32_t sample, uint32_t npix, double* org, double* dir,
                          uint32_t max_blocks, hipStream_t s);
-void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, const uint32_t* count_ptr, uint32_t* next_ray,
+void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, const uint32_t* count_ptr,
                      uint64_t max_count, double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool exact,
                      uint32_t max_blocks, hipStream_t s);
 void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const uint32_t* count_in,

@@ -18,6 +18,19 @@ namespace rtx {
 
 constexpr int BLOCK = 256;
 
+#ifndef RTX_SPHERE_PREFETCH
+#define RTX_SPHERE_PREFETCH 0
+#endif
+#ifndef RTX_TRAVERSE_WAVES
+#define RTX_TRAVERSE_WAVES 1
+#endif
+#ifndef RTX_SHADE_WAVES
+#define RTX_SHADE_WAVES 1
+#endif
+#ifndef RTX_REFILL_AT
+#define RTX_REFILL_AT 64
+#endif
+
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 __device__ __forceinline__ uint32_t rank_below(unsigned long long mask, uint32_t lane) {
     return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -123,19 +136,18 @@ __global__ __launch_bounds__(BLOCK) void k_primary_rays(DCamera cam, uint64_t se
 // shrinking interval and the tie rule (`hit.t > nearest.t` keeps the old hit,
 // :159-167) are exactly the reference's.
 //
-// Shape of the kernel.  Waves are persistent: a lane that has finished its
-// ray takes the next one from a global counter (one atomic per wave), so
-// short rays do not leave lanes idle while long ones finish.  Each wave
-// alternates two phases: all lanes walk nodes until they stand on a leaf
+// Shape of the kernel.  Each wave works through tiles of 64 consecutive rays
+// and alternates two phases: all lanes walk nodes until they stand on a leaf
 // whose box is hit (or run out of tree), then the lanes that found one test
 // their surface together.  A ray's own sequence of box and surface tests is
 // unchanged by this; only when the wave executes them is.
 template <bool COUNT, bool EXACT>
-__global__ __launch_bounds__(BLOCK) void k_traverse(DScene sc, DState rays, DHits hits, const uint32_t* count_ptr,
-                                                    uint32_t* next_ray, double tmin, double tmax0, DRenderCtl* ctl) {
-    constexpr uint32_t REFILL_AT = 16;   // fetch new rays once this many lanes are idle
+__global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene sc, DState rays, DHits hits, const uint32_t* count_ptr,
+                                                                        double tmin, double tmax0, DRenderCtl* ctl) {
     const uint32_t count = *count_ptr;
     const uint32_t lane = lane_id();
+    const uint32_t tile_stride = gridDim.x * BLOCK;
+    uint32_t tile_base = (blockIdx.x * BLOCK + threadIdx.x) & ~63u;   // first ray of this wave's current tile
     const uint32_t end = sc.n_nodes;
     const bool scene_filter = !EXACT && sc.filter_ok != 0u;
 
@@ -148,71 +160,68 @@ __global__ __launch_bounds__(BLOCK) void k_traverse(DScene sc, DState rays, DHit
     filter_set_tmin(fb, tmin);
     filter_set_tmax(fb, tmax0);
     uint32_t c_nodes = 0, c_sph = 0, c_pln = 0;
-    bool more = true;      // the counter has not run past `count` yet (wave-uniform)
 
     for (;;) {
-        // ---- refill
-        const unsigned long long idle = __ballot(idx == NONE);
-        const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (more && (n_idle >= REFILL_AT)) {
-            const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(next_ray, n_idle);
-            base = __shfl(base, leader);
-            if (base + n_idle >= count) more = false;
-            if (idx == NONE) {
-                const uint32_t mine = base + rank_below(idle, lane);
-                if (mine < count) {
-                    idx = mine;
-                    o = v3(rays.ox[mine], rays.oy[mine], rays.oz[mine]);
-                    d = v3(rays.dx[mine], rays.dy[mine], rays.dz[mine]);
-                    tmax = tmax0;
-                    best_t = tmax0;
-                    best_prim = NONE;
-                    node = 0;
-                    filtered = scene_filter && filter_ray_ok(o, d, tmin, tmax0);
-                    inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-                    filter_set_tmax(fb, tmax0);
-                }
-            }
-        }
+        // ---- refill: when every lane has retired, the wave takes its next tile of 64 rays.
+        // Tiles are dealt round-robin over the waves of the grid; a shared work
+        // counter would serialise on one L2 word (one atomic per 64 rays).
         if (__ballot(idx != NONE) == 0ull) {
-            if (!more) break;
-            continue;   // fewer than REFILL_AT lanes were idle a moment ago and all have retired since
+            if (tile_base >= count) break;
+            const uint32_t mine = tile_base + lane;
+            tile_base += tile_stride;
+            if (mine < count) {
+                idx = mine;
+                o = v3(rays.ox[mine], rays.oy[mine], rays.oz[mine]);
+                d = v3(rays.dx[mine], rays.dy[mine], rays.dz[mine]);
+                tmax = tmax0;
+                best_t = tmax0;
+                best_prim = NONE;
+                node = 0;
+                filtered = scene_filter && filter_ray_ok(o, d, tmin, tmax0);
+                inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                filter_set_tmax(fb, tmax0);
+            }
         }
 
         // ---- phase 1: walk to the next leaf whose box is hit
         bool searching = idx != NONE && node < end;
         bool pending = false;
         uint32_t leaf_kind = 0, leaf_slot = 0, leaf_prim = NONE;
+        double2 sph_a = make_double2(0.0, 0.0), sph_b = make_double2(0.0, 0.0);
         while (__ballot(searching) != 0ull) {
             if (searching) {
-                const DNode& nd = sc.nodes[node];
+                // the whole 64-byte record in four 16-byte loads issued back to back
+                const double2* np = reinterpret_cast<const double2*>(sc.nodes + node);
+                const double2 q0 = np[0], q1 = np[1], q2 = np[2];
+                const uint4 link = *reinterpret_cast<const uint4*>(np + 3);   // miss, prim, kind, slot
+                const double bmin[3] = {q0.x, q0.y, q1.x};
+                const double bmax[3] = {q1.y, q2.x, q2.y};
                 if (COUNT) ++c_nodes;
                 bool hit;
-                if (filtered) {
-                    int r = box_hit_filtered(nd.bmin, nd.bmax, o, inv, fb);
+                if (EXACT) {
+                    hit = box_hit_exact(bmin, bmax, o, d, tmin, tmax);
+                } else {
+                    const int r = box_hit_filtered(bmin, bmax, o, inv, fb);
                     hit = r > 0;
-                    if (r < 0) hit = box_hit_exact_slow(nd.bmin, nd.bmax, o, d, tmin, tmax);
-                } else if (EXACT) {
-                    hit = box_hit_exact(nd.bmin, nd.bmax, o, d, tmin, tmax);
-                } else {
-                    hit = box_hit_exact_slow(nd.bmin, nd.bmax, o, d, tmin, tmax);
+                    if (!filtered || r < 0) hit = box_hit_exact_slow(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, o, d, tmin, tmax);
                 }
-                const uint32_t prim = nd.prim;
-                if (!hit) {
-                    node = nd.miss;
-                } else if (prim == NONE) {
-                    node = node + 1u;
-                } else {
+                const bool leaf = link.y != NONE;
+                const bool found = hit && leaf;
+                node = (hit && !leaf) ? node + 1u : link.x;   // a leaf's successor is link.x as well
+                if (found) {
                     pending = true;
-                    leaf_prim = prim;
-                    leaf_kind = nd.kind;
-                    leaf_slot = nd.slot;
-                    node = nd.miss;   // a leaf's successor is the next node
-                    searching = false;
+                    leaf_prim = link.y;
+                    leaf_kind = link.z;
+                    leaf_slot = link.w;
+#if RTX_SPHERE_PREFETCH
+                    if (link.z == 0u) {   // start fetching the sphere while other lanes keep walking
+                        const double2* sp = reinterpret_cast<const double2*>(sc.spheres + link.w);
+                        sph_a = sp[0];
+                        sph_b = sp[1];
+                    }
+#endif
                 }
-                if (node >= end) searching = false;
+                searching = !found && node < end;
             }
         }
 
@@ -222,7 +231,14 @@ __global__ __launch_bounds__(BLOCK) void k_traverse(DScene sc, DState rays, DHit
             bool ph;
             if (leaf_kind == 0u) {
                 if (COUNT) ++c_sph;
-                ph = sphere_t(sc.spheres[leaf_slot], o, d, tmin, tmax, t);
+#if !RTX_SPHERE_PREFETCH
+                const double2* spp = reinterpret_cast<const double2*>(sc.spheres + leaf_slot);
+                sph_a = spp[0];
+                sph_b = spp[1];
+#endif
+                DSphere sp;
+                sp.c[0] = sph_a.x; sp.c[1] = sph_a.y; sp.c[2] = sph_b.x; sp.r = sph_b.y;
+                ph = sphere_t(sp, o, d, tmin, tmax, t);
             } else {
                 if (COUNT) ++c_pln;
                 double al, be;
@@ -269,12 +285,15 @@ __device__ __forceinline__ double reflectance(double cos_theta, double refractio
 // The reference nests `emitted + ray_color(..) * attenuation`; with emission
 // only on surfaces that do not scatter this is the same product of
 // attenuations, associated from the other end.
-__global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DState cur, DHits hits, const uint32_t* count_in,
+__global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCamera cam, DState cur, DHits hits, const uint32_t* count_in,
                                                  DState nxt, uint32_t* count_out, uint64_t seed, double* accum) {
+    __shared__ uint32_t wave_total[BLOCK / 64];
+    __shared__ uint32_t block_base;
     const uint32_t count = *count_in;
     const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
     const uint32_t stride = gridDim.x * BLOCK;
-    // the loop bound is wave-uniform so every lane reaches the ballot
+    // the loop bound is block-uniform so every thread reaches the barriers
     const uint32_t rounds = (count + stride - 1) / stride;
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t i = r * stride + blockIdx.x * BLOCK + threadIdx.x;
@@ -374,20 +393,38 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DState 
                     alive = true;
                 }
             }
+#ifdef RTX_EXPERIMENT_NO_ATOMICS   // timing experiment only
+            if (add && radiance.x == 123.456) {
+#else
             if (add) {
+#endif
                 double* px = accum + 3 * (size_t)pixel;
                 if (radiance.x != 0.0) unsafeAtomicAdd(px + 0, radiance.x);
                 if (radiance.y != 0.0) unsafeAtomicAdd(px + 1, radiance.y);
                 if (radiance.z != 0.0) unsafeAtomicAdd(px + 2, radiance.z);
             }
         }
-        // compaction: surviving paths go densely into the other state buffer
+        // compaction: surviving paths go densely into the other state buffer.
+        // 64-wide ballot + prefix popcount inside a wave, wave totals summed
+        // through LDS, and ONE atomic per block and round: a returning atomic
+        // on a single L2 word sustains under 100 operations per microsecond,
+        // which one atomic per wave would exceed.
         const unsigned long long amask = __ballot(alive);
-        if (amask) {
-            const uint32_t leader = (uint32_t)__ffsll((long long)amask) - 1u;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(count_out, (uint32_t)__popcll(amask));
-            base = __shfl(base, leader);
+        if (lane == 0) wave_total[wave] = (uint32_t)__popcll(amask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < BLOCK / 64; ++w) {
+                const uint32_t c = wave_total[w];
+                wave_total[w] = total;   // exclusive prefix
+                total += c;
+            }
+            block_base = total ? atomicAdd(count_out, total) : 0u;
+        }
+        __syncthreads();
+        {
+            const uint32_t base = block_base + wave_total[wave];
             if (alive) {
                 const uint32_t k = base + rank_below(amask, lane);
                 nxt.ox[k] = p.x; nxt.oy[k] = p.y; nxt.oz[k] = p.z;
@@ -399,6 +436,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DCamera cam, DState 
                 nxt.depth[k] = depth;
             }
         }
+        __syncthreads();   // wave_total / block_base are reused by the next round
     }
 }
 
@@ -461,16 +499,16 @@ void launch_primary_rays(const DCamera& cam, uint64_t seed, uint32_t sample, uin
                          uint32_t max_blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_primary_rays, dim3(grid_for(npix, max_blocks)), dim3(BLOCK), 0, s, cam, seed, sample, npix, org, dir);
 }
-void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, const uint32_t* count_ptr, uint32_t* next_ray,
+void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, const uint32_t* count_ptr,
                      uint64_t max_count, double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool exact,
                      uint32_t max_blocks, hipStream_t s) {
     dim3 g(grid_for(max_count, max_blocks)), b(BLOCK);
     if (count_work) {
-        if (exact) hipLaunchKernelGGL((k_traverse<true, true>), g, b, 0, s, sc, rays, hits, count_ptr, next_ray, tmin, tmax, ctl);
-        else hipLaunchKernelGGL((k_traverse<true, false>), g, b, 0, s, sc, rays, hits, count_ptr, next_ray, tmin, tmax, ctl);
+        if (exact) hipLaunchKernelGGL((k_traverse<true, true>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
+        else hipLaunchKernelGGL((k_traverse<true, false>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
     } else {
-        if (exact) hipLaunchKernelGGL((k_traverse<false, true>), g, b, 0, s, sc, rays, hits, count_ptr, next_ray, tmin, tmax, ctl);
-        else hipLaunchKernelGGL((k_traverse<false, false>), g, b, 0, s, sc, rays, hits, count_ptr, next_ray, tmin, tmax, ctl);
+        if (exact) hipLaunchKernelGGL((k_traverse<false, true>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
+        else hipLaunchKernelGGL((k_traverse<false, false>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
     }
 }
 void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const uint32_t* count_in,

@@ -229,10 +229,10 @@ def test_metal_absorbs_below_surface(oracle):
     absorbed = [x for x in outs if not x["scattered"]]
     assert 40 < len(absorbed) < 160
     assert all(np.array_equal(x["emitted"], [0, 0, 0]) for x in outs)
-    # fuzz 0 still draws a unit vector (at least 3 doubles)
+    # fuzz 0 still draws a unit vector (one block per rejection trial)
     m0 = S.quad((0, 0, 0), (1, 0, 0), (0, 1, 0), S.metal((0.8, 0.8, 0.8), 0.0))
     r = oracle.scatter(m0, o, d, h["raw"], seed=9, pixel=0, sample=0, draw=0)
-    assert r["scattered"] and r["draw"] >= 3 and r["draw"] % 3 == 0
+    assert r["scattered"] and r["draw"] >= 2 and r["draw"] % 2 == 0
 
 
 def test_lambertian_and_lights(oracle):
@@ -243,7 +243,7 @@ def test_lambertian_and_lights(oracle):
     for p in range(2000):
         r = oracle.scatter(lam, o, d, h["raw"], seed=1, pixel=p, sample=0, draw=1)   # odd draw index rounds up to 2
         assert r["scattered"] and np.array_equal(r["attenuation"], [0.1, 0.2, 0.3]) and np.array_equal(r["origin"], h["p"])
-        assert r["draw"] >= 5 and (r["draw"] - 2) % 3 == 0
+        assert r["draw"] >= 4 and r["draw"] % 2 == 0
         dirs.append(r["direction"])
     dirs = np.array(dirs)
     u = dirs - h["normal"]                       # the random unit vector
