@@ -113,7 +113,9 @@ typedef struct rtx_scene rtx_scene;
 /* flags for rtx_render_accumulate / rtx_trace_closest */
 #define RTX_FLAG_COUNT_WORK   1u  /* fill node_visits / *_tests (slower) */
 #define RTX_FLAG_TIME_KERNELS 2u  /* time every traverse / shade launch with HIP events */
-#define RTX_FLAG_EXACT_DIVIDE 4u  /* box test by six true divisions per node instead of the filtered form */
+#define RTX_FLAG_EXACT_DIVIDE 4u  /* box test by six true divisions per node, exactly as src/aabb.rs:55-76 */
+#define RTX_FLAG_F64_FILTER   8u  /* skip the single-precision tier of the box test */
+#define RTX_FLAG_NO_LDS       16u /* keep the f32 node records in global memory even when they fit in LDS */
 
 /* Message of the calling thread's last failed call. */
 const char* rtx_last_error(void);

@@ -30,6 +30,8 @@ NONE = 0xFFFFFFFF
 FLAG_COUNT_WORK = 1
 FLAG_TIME_KERNELS = 2
 FLAG_EXACT_DIVIDE = 4
+FLAG_F64_FILTER = 8
+FLAG_NO_LDS = 16
 
 BISECT, MIDPOINT, SAH_EQUAL_SIZE, SAH_PER_SURFACE = 0, 1, 2, 3
 

@@ -73,6 +73,10 @@ struct rtx_scene {
     DevBuf<DPlanar> planars;
     DevBuf<DPrimInfo> prims;
     DevBuf<DMaterial> materials;
+    DevBuf<DNode32> nodes32;
+    DevBuf<DBox64> boxes64;
+    DevBuf<uint32_t> sphere_prim, planar_prim;
+    bool f32_ok = false;   // every box plane is small enough for the single-precision tier
     // path state (two buffers, ping-pong) and hit records, sized on first use and kept
     size_t capacity = 0;
     DevBuf<double> buf_f64;     // 2 x 9 state arrays + hit_t
@@ -174,6 +178,11 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     // one forward pass fills every successor: the left child (i+1) is
     // followed by the right child, the right child by the parent's successor.
     std::vector<DNode> nodes(n);
+    std::vector<DNode32> nodes32(n);
+    std::vector<DBox64> boxes64(n);
+    std::vector<uint32_t> sphere_prim, planar_prim;
+    for (uint32_t i = 0; i < m; ++i) (prims[i].kind == RTX_SPHERE ? sphere_prim : planar_prim).push_back(i);
+    bool f32_ok = true;
     std::vector<uint32_t> miss(n, NONE);
     bool filter_ok = true;
     if (n) miss[0] = n;
@@ -183,6 +192,11 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
             nd.bmin[a] = desc->node_bmin[(size_t)a * n + i];
             nd.bmax[a] = desc->node_bmax[(size_t)a * n + i];
             if (!(std::fabs(nd.bmin[a]) <= 0x1.0p300) || !(std::fabs(nd.bmax[a]) <= 0x1.0p300)) filter_ok = false;
+            if (!(std::fabs(nd.bmin[a]) <= 1e15) || !(std::fabs(nd.bmax[a]) <= 1e15)) f32_ok = false;
+            boxes64[i].bmin[a] = nd.bmin[a];
+            boxes64[i].bmax[a] = nd.bmax[a];
+            nodes32[i].plane[2 * a] = (float)nd.bmin[a];
+            nodes32[i].plane[2 * a + 1] = (float)nd.bmax[a];
         }
         if (miss[i] == NONE) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: node " + std::to_string(i) + " is not reachable in pre-order");
         if (miss[i] <= i || miss[i] > n) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: malformed tree");
@@ -196,15 +210,19 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
             nd.prim = prim;
             nd.kind = prims[prim].kind;
             nd.slot = prims[prim].slot;
+            if (nd.slot >= (1u << 30)) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: more than 2^30 surfaces of one kind");
+            nodes32[i].leaf = (nd.kind << 30) | nd.slot;
         } else {                  // Node::Internal(Some(right_idx), box)
             if (right == RTX_NONE || right <= i + 1 || right >= miss[i])
                 return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: right child index out of order at node " + std::to_string(i));
             nd.prim = NONE;
             nd.kind = 0;
             nd.slot = 0;
+            nodes32[i].leaf = NONE;
             miss[i + 1] = right;
             miss[right] = miss[i];
         }
+        nodes32[i].miss = nd.miss;
     }
 
     rtx_scene* sc = new rtx_scene();
@@ -228,6 +246,10 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     UP(planars, planars);
     UP(prims, prims);
     UP(materials, mats);
+    UP(nodes32, nodes32);
+    UP(boxes64, boxes64);
+    UP(sphere_prim, sphere_prim);
+    UP(planar_prim, planar_prim);
 #undef UP
     sc->d.nodes = sc->nodes.p;
     sc->d.spheres = sc->spheres.p;
@@ -237,6 +259,11 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     sc->d.n_nodes = n;
     sc->d.n_prims = m;
     sc->d.filter_ok = filter_ok ? 1u : 0u;
+    sc->d.nodes32 = sc->nodes32.p;
+    sc->d.boxes64 = sc->boxes64.p;
+    sc->d.sphere_prim = sc->sphere_prim.p;
+    sc->d.planar_prim = sc->planar_prim.p;
+    sc->f32_ok = f32_ok && filter_ok;
     if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
         return bail(fail(RTX_ERR_HIP, "hipEventCreate failed"));
     *out = sc;
@@ -250,6 +277,24 @@ void rtx_scene_destroy(rtx_scene* sc) {
     for (hipEvent_t e : sc->kernel_events) (void)hipEventDestroy(e);
     if (sc->h_count) (void)hipHostFree(sc->h_count);
     delete sc;
+}
+
+// Which closest-hit kernel a call uses: the reference's division form when the
+// caller asks for it, else the tiered test with the f32 records in LDS (small
+// trees), from global memory (large trees), or the f64-only filter (scenes
+// whose box planes are too large for f32, or on request).
+static void run_traverse(rtx_scene* sc, const DState& rays, const uint32_t* count_ptr, uint64_t max_count, double tmin, double tmax,
+                         uint32_t flags, uint32_t max_blocks, hipStream_t s) {
+    const bool count_work = (flags & RTX_FLAG_COUNT_WORK) != 0;
+    const uint32_t lds_limit = env_u32("RTX_LDS_NODE_BYTES", 40u * 1024u);
+    if (flags & RTX_FLAG_EXACT_DIVIDE) {
+        launch_traverse(sc->d, rays, sc->hits, count_ptr, max_count, tmin, tmax, sc->ctl.p, count_work, true, max_blocks, s);
+    } else if ((flags & RTX_FLAG_F64_FILTER) || !sc->f32_ok) {
+        launch_traverse(sc->d, rays, sc->hits, count_ptr, max_count, tmin, tmax, sc->ctl.p, count_work, false, max_blocks, s);
+    } else {
+        const bool lds = !(flags & RTX_FLAG_NO_LDS) && (size_t)sc->d.n_nodes * sizeof(DNode32) <= lds_limit;
+        launch_traverse_f32(sc->d, rays, sc->hits, count_ptr, max_count, tmin, tmax, sc->ctl.p, count_work, lds, max_blocks, s);
+    }
 }
 
 static int read_counters(rtx_scene* sc, hipStream_t s, rtx_stats* stats) {
@@ -284,8 +329,7 @@ int rtx_trace_closest(rtx_scene* sc, const double* org, const double* dir, uint6
     launch_rays_to_state(d_rays.p, d_rays.p + 3 * n, n, sc->state[0], s);
     const uint32_t max_blocks = sc->n_cus * env_u32("RTX_BLOCKS_PER_CU", 8);
     HIP_TRY(hipEventRecord(sc->ev0, s));
-    launch_traverse(sc->d, sc->state[0], sc->hits, &sc->ctl.p->count_live, n, tmin, tmax, sc->ctl.p,
-                    (flags & RTX_FLAG_COUNT_WORK) != 0, (flags & RTX_FLAG_EXACT_DIVIDE) != 0, max_blocks, s);
+    run_traverse(sc, sc->state[0], &sc->ctl.p->count_live, n, tmin, tmax, flags, max_blocks, s);
     HIP_TRY(hipEventRecord(sc->ev1, s));
     launch_user_ids(sc->d.prims, sc->hits.prim, n, s);
     HIP_TRY(hipGetLastError());
@@ -366,8 +410,6 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     if (rc != RTX_OK) return rc;
     const uint32_t max_blocks = sc->n_cus * env_u32("RTX_BLOCKS_PER_CU", 8);
     const uint32_t check_every = env_u32("RTX_CHECK_EVERY", 4);
-    const bool count_work = (flags & RTX_FLAG_COUNT_WORK) != 0;
-    const bool exact = (flags & RTX_FLAG_EXACT_DIVIDE) != 0;
     const bool time_kernels = (flags & RTX_FLAG_TIME_KERNELS) != 0;
     const DCamera dcam = to_dcamera(cam);
 
@@ -406,8 +448,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         }
         launch_generate(dcam, sc->state[cur], slots, ctl, cur, seed, spp_begin, max_blocks, s);
         if (time_kernels) (void)hipEventRecord(e0, s);
-        launch_traverse(sc->d, sc->state[cur], sc->hits, &ctl->count_live, slots, 0.001, INFINITY, ctl,
-                        count_work, exact, max_blocks, s);   // Interval(0.001, inf), camera.rs:194
+        run_traverse(sc, sc->state[cur], &ctl->count_live, slots, 0.001, INFINITY, flags, max_blocks, s);   // Interval(0.001, inf), camera.rs:194
         if (time_kernels) (void)hipEventRecord(e1, s);
         launch_shade(sc->d, dcam, sc->state[cur], sc->hits, &ctl->count_live, sc->state[nxt], &ctl->count_surv[nxt], slots, seed,
                      d_accum, max_blocks, s);

@@ -29,6 +29,22 @@ struct __attribute__((aligned(64))) DNode {
 };
 static_assert(sizeof(DNode) == 64, "node record must be one 64-byte line");
 
+// Single-precision copy of a node for the first tier of the box test: the box
+// planes rounded to f32, interleaved per axis so that one packed multiply-add
+// yields both slab distances of an axis, and the two links.  32 bytes: two
+// 16-byte loads per visit, half of the f64 record.
+struct __attribute__((aligned(32))) DNode32 {
+    float plane[6];   // lo.x, hi.x, lo.y, hi.y, lo.z, hi.z
+    uint32_t miss;    // as DNode::miss
+    uint32_t leaf;    // NONE for an internal node, else (geometry kind << 30) | slot
+};
+static_assert(sizeof(DNode32) == 32, "f32 node record must be 32 bytes");
+// The exact box of a node, for the rare visits the f32 tier cannot decide.
+struct __attribute__((aligned(16))) DBox64 {
+    double bmin[3];
+    double bmax[3];
+};
+
 struct __attribute__((aligned(32))) DSphere {   // Geometry::Sphere, src/geometry.rs:27-30
     double c[3];
     double r;
@@ -56,6 +72,10 @@ struct DScene {
     uint32_t n_nodes;
     uint32_t n_prims;
     uint32_t filter_ok;   // every box coordinate is finite and small enough for the filtered box test
+    const DNode32* nodes32;
+    const DBox64* boxes64;
+    const uint32_t* sphere_prim;   // slot in the sphere table -> prim index
+    const uint32_t* planar_prim;   // slot in the planar table -> prim index
 };
 
 // State of the paths in flight, struct-of-arrays.  Entry i of every array
@@ -300,6 +320,77 @@ __device__ __forceinline__ bool filter_comp_ok(double d) {
 __device__ __forceinline__ bool filter_ray_ok(V3 o, V3 d, double tmin, double tmax) {
     return filter_comp_ok(d.x) && filter_comp_ok(d.y) && filter_comp_ok(d.z) && fabs(o.x) <= 0x1.0p300 &&
            fabs(o.y) <= 0x1.0p300 && fabs(o.z) <= 0x1.0p300 && tmin >= 0x1.0p-900 && tmin < tmax;
+}
+
+// ---------------------------------------------------------------- f32 first tier
+// The same three comparisons (hi* > tmin, lo* < tmax, lo* < hi*), first tried
+// in single precision.  With b32 = RN32(b), inv32 = RN32(RN64(1/d)),
+// oi32 = RN32(RN64(-o * RN64(1/d))) the slab distance t~ = b32*inv32 + oi32,
+// evaluated in f32 with or without fusing, differs from the real quotient
+// (b - o)/d by at most
+//     2^-24 * (3|b/d| + |o/d| + |t~|) * (1 + 2^-20)
+// (one rounding each for b32, inv32, oi32, the product and the sum; the f64
+// roundings behind inv and oi are 2^-29 times smaller).  With
+// |b/d| <= mag*|inv32|(1 + 2^-23), mag = the larger plane magnitude of the
+// axis, and |t~| <= |b32*inv32| + |oi32|, this is below
+//     e_axis = mag * A_axis + B_axis,  A = 4.04 * 2^-24 * |inv32|,  B = 2.02 * 2^-24 * |oi32|,
+// and max/min over the axes move lo and hi by at most E = max_axis e_axis.
+// The reference's own f64 rounding of each quotient (2^-53 relative) is
+// inside the 1 % slack of the constants.  A comparison is accepted only if
+// it holds with E (and a 2^-20 relative guard on tmin/tmax for the f32
+// rounding of the subtraction) to spare; anything else, including any NaN or
+// infinity produced on the way, leaves the visit undecided and it is
+// repeated in f64.  To keep every f32 operation inside the normal range
+// (where the 2^-24 relative rounding model holds, and no NaN or infinity can
+// arise that min/max would silently drop) a ray takes this tier only if
+// 1e-30 <= |inv32| <= 1e15 and |oi32| <= 1e15 on every axis with oi32 either
+// zero or at least 1e-30, and a scene only if every box plane is at most
+// 1e15 in magnitude; the absolute term 1e-30 in B covers planes so small that
+// their f32 copy is subnormal.
+struct RayF32 {
+    float inv[3], oi[3], A[3], B[3];
+    float tmin_up, tmin_dn, tmax_up, tmax_dn;
+};
+__device__ __forceinline__ void rayf32_set_tmax(RayF32& r, double tmax) {
+    const float t = (float)tmax;
+    r.tmax_up = t * (1.0f + 0x1.0p-20f);
+    r.tmax_dn = t * (1.0f - 0x1.0p-20f);
+}
+// returns false when the ray must skip the f32 tier
+__device__ __forceinline__ bool rayf32_init(RayF32& r, V3 o, V3 inv, double tmin, double tmax) {
+    const double iv[3] = {inv.x, inv.y, inv.z};
+    const double ov[3] = {o.x, o.y, o.z};
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        r.inv[a] = (float)iv[a];
+        r.oi[a] = (float)(-ov[a] * iv[a]);
+        const float ai = fabsf(r.inv[a]), ao = fabsf(r.oi[a]);
+        ok = ok && ai >= 1e-30f && ai <= 1e15f && ao <= 1e15f && (ao == 0.0f || ao >= 1e-30f);
+        r.A[a] = ai * (4.04f * 0x1.0p-24f);
+        r.B[a] = ao * (2.02f * 0x1.0p-24f) + 1e-30f;
+    }
+    const float t = (float)tmin;
+    r.tmin_up = t * (1.0f + 0x1.0p-20f);
+    r.tmin_dn = t * (1.0f - 0x1.0p-20f);
+    rayf32_set_tmax(r, tmax);
+    return ok && t >= 1e-30f && t <= 1e15f;
+}
+// 1 = hit for certain, 0 = miss for certain, -1 = undecided
+__device__ __forceinline__ int box_hit_f32(const float p[6], const RayF32& r) {
+    const float t0x = fmaf(p[0], r.inv[0], r.oi[0]), t1x = fmaf(p[1], r.inv[0], r.oi[0]);
+    const float t0y = fmaf(p[2], r.inv[1], r.oi[1]), t1y = fmaf(p[3], r.inv[1], r.oi[1]);
+    const float t0z = fmaf(p[4], r.inv[2], r.oi[2]), t1z = fmaf(p[5], r.inv[2], r.oi[2]);
+    const float ex = fmaf(fmaxf(fabsf(p[0]), fabsf(p[1])), r.A[0], r.B[0]);
+    const float ey = fmaf(fmaxf(fabsf(p[2]), fabsf(p[3])), r.A[1], r.B[1]);
+    const float ez = fmaf(fmaxf(fabsf(p[4]), fabsf(p[5])), r.A[2], r.B[2]);
+    const float E = fmaxf(fmaxf(ex, ey), ez) * 1.001f;
+    const float lo = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    const float hi = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    const float E2 = E + E;
+    const bool hit = (hi - E > r.tmin_up) && (lo + E < r.tmax_dn) && (hi - lo > E2);
+    const bool miss = (hi + E < r.tmin_dn) || (lo - E > r.tmax_up) || (lo - hi > E2);
+    return hit ? 1 : (miss ? 0 : -1);
 }
 
 // ---------------------------------------------------------------- primitive tests

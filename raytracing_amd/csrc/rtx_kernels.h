@@ -11,6 +11,9 @@ void launch_primary_rays(const DCamera& cam, uint64_t seed, uint32_t sample, uin
 void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, const uint32_t* count_ptr,
                      uint64_t max_count, double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool exact,
                      uint32_t max_blocks, hipStream_t s);
+void launch_traverse_f32(const DScene& sc, const DState& rays, const DHits& hits, const uint32_t* count_ptr, uint64_t max_count,
+                         double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool lds_nodes, uint32_t max_blocks,
+                         hipStream_t s);
 void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const uint32_t* count_in,
                   const DState& nxt, uint32_t* count_out, uint64_t max_count, uint64_t seed, double* accum, uint32_t max_blocks,
                   hipStream_t s);

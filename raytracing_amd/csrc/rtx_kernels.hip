@@ -123,6 +123,23 @@ __global__ __launch_bounds__(BLOCK) void k_primary_rays(DCamera cam, uint64_t se
     }
 }
 
+// Second and third tier of the box test, out of line: the f64 filter on the
+// exact box and, if that is undecided too or the ray is outside the filter's
+// preconditions, the reference's division form.
+__device__ __noinline__ bool tier2_box(double2 q0, double2 q1, double2 q2, V3 o, V3 d, double tmin, double tmax, bool use_filter) {
+    const double bmin[3] = {q0.x, q0.y, q1.x};
+    const double bmax[3] = {q1.y, q2.x, q2.y};
+    if (use_filter) {
+        const V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+        FilterBounds fb;
+        filter_set_tmin(fb, tmin);
+        filter_set_tmax(fb, tmax);
+        const int r = box_hit_filtered(bmin, bmax, o, inv, fb);
+        if (r >= 0) return r > 0;
+    }
+    return box_hit_exact(bmin, bmax, o, d, tmin, tmax);
+}
+
 // ---------------------------------------------------------------- closest hit
 // impl Hittable for BVH::hit, src/bvh/mod.rs:134-174.
 //
@@ -256,6 +273,142 @@ __global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene s
         // ---- retire rays that have run out of tree
         if (idx != NONE && node >= end) {
             hits.prim[idx] = best_prim;
+            hits.t[idx] = best_t;
+            idx = NONE;
+        }
+    }
+    if (COUNT && ctl) {
+        atomicAdd(&ctl->node_visits, (unsigned long long)c_nodes);
+        atomicAdd(&ctl->sphere_tests, (unsigned long long)c_sph);
+        atomicAdd(&ctl->planar_tests, (unsigned long long)c_pln);
+    }
+}
+
+// The same walk with the box test in three tiers: single precision from a
+// 32-byte node record (box_hit_f32); if that cannot decide, the f64 filter on
+// the exact box (box_hit_filtered); if that cannot decide either, the
+// reference's six divisions.  Every tier either proves what the reference's
+// predicate returns or hands the visit on, so the sequence of nodes visited
+// and of surfaces tested is the reference's for every ray.  With LDS_NODES
+// the f32 records of the whole tree are first copied into LDS (scenes up to a
+// few thousand nodes), so a visit costs two LDS reads and no trip through the
+// vector cache.
+template <bool COUNT, bool LDS_NODES>
+__global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, DHits hits, const uint32_t* count_ptr,
+                                                        double tmin, double tmax0, DRenderCtl* ctl) {
+    extern __shared__ uint4 lds_nodes[];   // LDS_NODES: 2 x uint4 per node
+    const uint32_t end = sc.n_nodes;
+    if (LDS_NODES) {
+        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes32);
+        for (uint32_t i = threadIdx.x; i < 2u * end; i += BLOCK) lds_nodes[i] = src[i];
+        __syncthreads();
+    }
+    const uint32_t count = *count_ptr;
+    const uint32_t lane = lane_id();
+    const uint32_t tile_stride = gridDim.x * BLOCK;
+    uint32_t tile_base = (blockIdx.x * BLOCK + threadIdx.x) & ~63u;
+    const bool scene_filter = sc.filter_ok != 0u;
+
+    uint32_t idx = NONE;   // ray of this lane, NONE = idle
+    V3 o = v3(0, 0, 0), d = v3(1, 1, 1);
+    double tmax = tmax0, best_t = tmax0;
+    uint32_t best_leaf = NONE, node = 0;
+    bool use_f32 = false, use_filter = false;
+    RayF32 rf;
+    rayf32_init(rf, o, d, tmin, tmax0);
+    uint32_t c_nodes = 0, c_sph = 0, c_pln = 0;
+
+    for (;;) {
+        // ---- when every lane has retired, the wave takes its next tile of 64 rays
+        if (__ballot(idx != NONE) == 0ull) {
+            if (tile_base >= count) break;
+            const uint32_t mine = tile_base + lane;
+            tile_base += tile_stride;
+            if (mine < count) {
+                idx = mine;
+                o = v3(rays.ox[mine], rays.oy[mine], rays.oz[mine]);
+                d = v3(rays.dx[mine], rays.dy[mine], rays.dz[mine]);
+                tmax = tmax0;
+                best_t = tmax0;
+                best_leaf = NONE;
+                node = 0;
+                use_filter = scene_filter && filter_ray_ok(o, d, tmin, tmax0);
+                const V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                use_f32 = rayf32_init(rf, o, inv, tmin, tmax0) && use_filter;
+            }
+        }
+
+        // ---- phase 1: walk to the next leaf whose box is hit
+        bool searching = idx != NONE && node < end;
+        bool pending = false;
+        uint32_t leaf = NONE;
+        while (__ballot(searching) != 0ull) {
+            if (searching) {
+                uint4 n0, n1;
+                if (LDS_NODES) {
+                    n0 = lds_nodes[2u * node];
+                    n1 = lds_nodes[2u * node + 1u];
+                } else {
+                    const uint4* np = reinterpret_cast<const uint4*>(sc.nodes32 + node);
+                    n0 = np[0];
+                    n1 = np[1];
+                }
+                if (COUNT) ++c_nodes;
+                const float planes[6] = {__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z),
+                                         __uint_as_float(n0.w), __uint_as_float(n1.x), __uint_as_float(n1.y)};
+                int r = box_hit_f32(planes, rf);
+                if (!use_f32) r = -1;
+                if (r < 0) {   // undecided in f32: the exact box, f64 filter, then the division form
+                    const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + node);
+                    const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
+                    r = tier2_box(q0, q1, q2, o, d, tmin, tmax, use_filter) ? 1 : 0;
+                }
+                const bool hit = r > 0;
+                const bool is_leaf = n1.w != NONE;
+                const bool found = hit && is_leaf;
+                node = (hit && !is_leaf) ? node + 1u : n1.z;   // a leaf's successor is its miss link as well
+                if (found) {
+                    pending = true;
+                    leaf = n1.w;
+                }
+                searching = !found && node < end;
+            }
+        }
+
+        // ---- phase 2: surface tests of the lanes standing on a leaf
+        if (pending) {
+            const uint32_t kind = leaf >> 30, slot = leaf & 0x3FFFFFFFu;
+            double t;
+            bool ph;
+            if (kind == 0u) {
+                if (COUNT) ++c_sph;
+                const double2* spp = reinterpret_cast<const double2*>(sc.spheres + slot);
+                const double2 sa = spp[0], sb = spp[1];
+                DSphere sp;
+                sp.c[0] = sa.x; sp.c[1] = sa.y; sp.c[2] = sb.x; sp.r = sb.y;
+                ph = sphere_t(sp, o, d, tmin, tmax, t);
+            } else {
+                if (COUNT) ++c_pln;
+                double al, be;
+                ph = planar_t(sc.planars[slot], kind, o, d, tmin, tmax, t, al, be);
+            }
+            // `if let Some(nearest) = acc && hit.t > nearest.t { keep } else { replace }`
+            if (ph && !(best_leaf != NONE && t > best_t)) {
+                best_leaf = leaf;
+                best_t = t;
+                tmax = t;   // shrunken_ray_t.max = hit.t
+                rayf32_set_tmax(rf, t);
+            }
+        }
+
+        // ---- retire rays that have run out of tree
+        if (idx != NONE && node >= end) {
+            uint32_t prim = NONE;
+            if (best_leaf != NONE) {
+                const uint32_t slot = best_leaf & 0x3FFFFFFFu;
+                prim = (best_leaf >> 30) == 0u ? sc.sphere_prim[slot] : sc.planar_prim[slot];
+            }
+            hits.prim[idx] = prim;
             hits.t[idx] = best_t;
             idx = NONE;
         }
@@ -509,6 +662,19 @@ void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, co
     } else {
         if (exact) hipLaunchKernelGGL((k_traverse<false, true>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
         else hipLaunchKernelGGL((k_traverse<false, false>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
+    }
+}
+void launch_traverse_f32(const DScene& sc, const DState& rays, const DHits& hits, const uint32_t* count_ptr, uint64_t max_count,
+                         double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool lds_nodes, uint32_t max_blocks,
+                         hipStream_t s) {
+    dim3 g(grid_for(max_count, max_blocks)), b(BLOCK);
+    const size_t lds = lds_nodes ? (size_t)sc.n_nodes * sizeof(DNode32) : 0;
+    if (lds_nodes) {
+        if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, true>), g, b, lds, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
+        else hipLaunchKernelGGL((k_traverse_f32<false, true>), g, b, lds, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
+    } else {
+        if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, false>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
+        else hipLaunchKernelGGL((k_traverse_f32<false, false>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
     }
 }
 void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const uint32_t* count_in,

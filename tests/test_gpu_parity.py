@@ -89,7 +89,7 @@ def test_primary_rays_bit_exact(rt, oracle, name):
 
 
 # ------------------------------------------------------------------ K2: closest hit
-@pytest.mark.parametrize("flags", [0, 4], ids=["filtered", "exact_divide"])
+@pytest.mark.parametrize("flags", [0, 16, 8, 4], ids=["f32_lds", "f32_global", "f64_filter", "exact_divide"])
 @pytest.mark.parametrize("name", EXAMPLES)
 def test_trace_closest_golden_vectors(rt, built, name, flags):
     """Committed vectors: ray batches with the oracle's ids and distances."""
@@ -150,12 +150,11 @@ def test_trace_closest_degenerate_rays(rt, oracle, built):
         d[rng.random((n, 3)) < 0.3] = 0.0                    # axis-parallel and zero directions
         org[: n // 4] = np.round(org[: n // 4])              # origins on integer planes (box faces in cornell)
         d[-8:] = [[np.inf, 1, 1], [np.nan, 0, 1], [1e-320, 1, 0], [1e305, 1, 1], [0, 0, 0], [-0.0, 1, 0], [1, -np.inf, 0], [1e-310, 1e-310, 1e-310]]
-        ids, t, _ = dev.trace_closest(org, d)
-        eids, et, _ = dev.trace_closest(org, d, flags=rt.FLAG_EXACT_DIVIDE)
         wid, wt, _ = orc.trace_closest(org, d)
-        assert np.array_equal(ids, wid) and np.array_equal(eids, wid)
-        assert np.array_equal(bits(t), bits(np.where(wid == NONE, np.inf, wt)))
-        assert np.array_equal(bits(et), bits(t))
+        for flags in (0, rt.FLAG_NO_LDS, rt.FLAG_F64_FILTER, rt.FLAG_EXACT_DIVIDE):
+            ids, t, _ = dev.trace_closest(org, d, flags=flags)
+            assert np.array_equal(ids, wid), flags
+            assert np.array_equal(bits(t), bits(np.where(wid == NONE, np.inf, wt))), flags
 
 
 def test_empty_and_single_surface_scene(rt, oracle):
