@@ -381,9 +381,10 @@ __device__ __forceinline__ int box_hit_f32(const float p[6], const RayF32& r) {
     const float t0x = fmaf(p[0], r.inv[0], r.oi[0]), t1x = fmaf(p[1], r.inv[0], r.oi[0]);
     const float t0y = fmaf(p[2], r.inv[1], r.oi[1]), t1y = fmaf(p[3], r.inv[1], r.oi[1]);
     const float t0z = fmaf(p[4], r.inv[2], r.oi[2]), t1z = fmaf(p[5], r.inv[2], r.oi[2]);
-    const float ex = fmaf(fmaxf(fabsf(p[0]), fabsf(p[1])), r.A[0], r.B[0]);
-    const float ey = fmaf(fmaxf(fabsf(p[2]), fabsf(p[3])), r.A[1], r.B[1]);
-    const float ez = fmaf(fmaxf(fabsf(p[4]), fabsf(p[5])), r.A[2], r.B[2]);
+    // larger plane magnitude of an axis: lo <= hi, so max(|lo|, |hi|) = max(-lo, hi)
+    const float ex = fmaf(fmaxf(-p[0], p[1]), r.A[0], r.B[0]);
+    const float ey = fmaf(fmaxf(-p[2], p[3]), r.A[1], r.B[1]);
+    const float ez = fmaf(fmaxf(-p[4], p[5]), r.A[2], r.B[2]);
     const float E = fmaxf(fmaxf(ex, ey), ez) * 1.001f;
     const float lo = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
     const float hi = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));

@@ -28,7 +28,10 @@ constexpr int BLOCK = 256;
 #define RTX_SHADE_WAVES 1
 #endif
 #ifndef RTX_REFILL_AT
-#define RTX_REFILL_AT 64
+#define RTX_REFILL_AT 32
+#endif
+#ifndef RTX_PEND_AT
+#define RTX_PEND_AT 16
 #endif
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
@@ -305,8 +308,19 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, 
     }
     const uint32_t count = *count_ptr;
     const uint32_t lane = lane_id();
-    const uint32_t tile_stride = gridDim.x * BLOCK;
-    uint32_t tile_base = (blockIdx.x * BLOCK + threadIdx.x) & ~63u;
+    // Tiles of 64 consecutive rays are dealt round-robin over the waves of the
+    // grid (neighbouring waves stream neighbouring memory).  A wave's own
+    // tiles form its private work list: position p of the list is ray
+    // (p & 63) of its (p >> 6)-th tile.  Idle lanes take the next positions
+    // of that list, so there is no shared work counter.
+    constexpr uint32_t REFILL_AT = RTX_REFILL_AT;   // refill once this many lanes are idle
+    constexpr uint32_t PEND_AT = RTX_PEND_AT;       // test surfaces once this many lanes stand on a leaf
+    const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+    const uint32_t wave_global = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const uint32_t n_tiles = (count + 63u) >> 6;
+    const uint32_t my_tiles = wave_global < n_tiles ? (n_tiles - wave_global + n_waves - 1u) / n_waves : 0u;
+    const uint32_t p_end = my_tiles * 64u;
+    uint32_t next_p = 0;
     const bool scene_filter = sc.filter_ok != 0u;
 
     uint32_t idx = NONE;   // ray of this lane, NONE = idle
@@ -317,14 +331,19 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, 
     RayF32 rf;
     rayf32_init(rf, o, d, tmin, tmax0);
     uint32_t c_nodes = 0, c_sph = 0, c_pln = 0;
+    bool pending = false;    // standing on a leaf whose box was hit, surface not tested yet
+    uint32_t leaf = NONE;
 
     for (;;) {
-        // ---- when every lane has retired, the wave takes its next tile of 64 rays
-        if (__ballot(idx != NONE) == 0ull) {
-            if (tile_base >= count) break;
-            const uint32_t mine = tile_base + lane;
-            tile_base += tile_stride;
-            if (mine < count) {
+        // ---- refill idle lanes from the wave's work list once enough of them are idle
+        const unsigned long long idle = __ballot(idx == NONE);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle == 64u && next_p >= p_end) break;
+        if (next_p < p_end && (n_idle >= REFILL_AT || n_idle == 64u)) {
+            const uint32_t p = next_p + rank_below(idle, lane);
+            next_p += n_idle;
+            const uint32_t mine = ((wave_global + (p >> 6) * n_waves) << 6) | (p & 63u);
+            if (idx == NONE && p < p_end && mine < count) {
                 idx = mine;
                 o = v3(rays.ox[mine], rays.oy[mine], rays.oz[mine]);
                 d = v3(rays.dx[mine], rays.dy[mine], rays.dz[mine]);
@@ -339,40 +358,39 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, 
         }
 
         // ---- phase 1: walk to the next leaf whose box is hit
+        // (a lane that found its leaf waits; the loop also ends as soon as
+        // PEND_AT lanes are waiting, so a few long searches do not stall them)
+        uint32_t n_pending = 0;   // wave-uniform
         bool searching = idx != NONE && node < end;
-        bool pending = false;
-        uint32_t leaf = NONE;
-        while (__ballot(searching) != 0ull) {
-            if (searching) {
-                uint4 n0, n1;
-                if (LDS_NODES) {
-                    n0 = lds_nodes[2u * node];
-                    n1 = lds_nodes[2u * node + 1u];
-                } else {
-                    const uint4* np = reinterpret_cast<const uint4*>(sc.nodes32 + node);
-                    n0 = np[0];
-                    n1 = np[1];
-                }
-                if (COUNT) ++c_nodes;
-                const float planes[6] = {__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z),
-                                         __uint_as_float(n0.w), __uint_as_float(n1.x), __uint_as_float(n1.y)};
-                int r = box_hit_f32(planes, rf);
-                if (!use_f32) r = -1;
-                if (r < 0) {   // undecided in f32: the exact box, f64 filter, then the division form
-                    const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + node);
-                    const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
-                    r = tier2_box(q0, q1, q2, o, d, tmin, tmax, use_filter) ? 1 : 0;
-                }
-                const bool hit = r > 0;
-                const bool is_leaf = n1.w != NONE;
-                const bool found = hit && is_leaf;
-                node = (hit && !is_leaf) ? node + 1u : n1.z;   // a leaf's successor is its miss link as well
-                if (found) {
-                    pending = true;
-                    leaf = n1.w;
-                }
-                searching = !found && node < end;
+        while (searching) {       // lanes leave the loop one by one; the wave stays until all have left
+            uint4 n0, n1;
+            if (LDS_NODES) {
+                n0 = lds_nodes[2u * node];
+                n1 = lds_nodes[2u * node + 1u];
+            } else {
+                const uint4* np = reinterpret_cast<const uint4*>(sc.nodes32 + node);
+                n0 = np[0];
+                n1 = np[1];
             }
+            if (COUNT) ++c_nodes;
+            const float planes[6] = {__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z),
+                                     __uint_as_float(n0.w), __uint_as_float(n1.x), __uint_as_float(n1.y)};
+            int r = box_hit_f32(planes, rf);
+            if (!use_f32) r = -1;
+            if (r < 0) {   // undecided in f32: the exact box, f64 filter, then the division form
+                const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + node);
+                const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
+                r = tier2_box(q0, q1, q2, o, d, tmin, tmax, use_filter) ? 1 : 0;
+            }
+            const bool hit = r > 0;
+            const bool is_leaf = n1.w != NONE;
+            const bool found = hit && is_leaf;
+            node = (hit && !is_leaf) ? node + 1u : n1.z;   // a leaf's successor is its miss link as well
+            leaf = found ? n1.w : leaf;
+            pending = found;
+            n_pending += (uint32_t)__popcll(__ballot(found));
+            searching = !found && node < end;
+            if (n_pending >= PEND_AT) break;   // wave-uniform
         }
 
         // ---- phase 2: surface tests of the lanes standing on a leaf
@@ -399,6 +417,7 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, 
                 tmax = t;   // shrunken_ray_t.max = hit.t
                 rayf32_set_tmax(rf, t);
             }
+            pending = false;
         }
 
         // ---- retire rays that have run out of tree
