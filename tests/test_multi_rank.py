@@ -1,0 +1,112 @@
+"""The N > 1 path on CPU: two gloo ranks each render their share of the
+sample indices (with the CPU oracle standing in for the device, which is
+what a test may do), the accumulation buffers are summed with the frame's one
+reduce, and rank 0 must hold the single-rank image."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SEED, SPP = 1234, 7
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _scene():
+    from raytracing_amd import scenes as S
+
+    surfaces, cam = S.cornell_box()
+    cam = dict(cam, image_width=24, samples_per_pixel=SPP)
+    return surfaces, cam
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pyoracle as po
+        from raytracing_amd import multi_gpu as mg
+
+        surfaces, cam = _scene()
+        sc = po.Scene(surfaces)
+        icam = po.camera_initialize(cam)
+        accum = torch.zeros(icam.image_height, icam.image_width, 3, dtype=torch.float64)
+
+        def render_accumulate(begin, count):
+            part, ctr = sc.render(icam, SEED, begin, count, n_threads=1, iterative=True)
+            accum.add_(torch.from_numpy(part))
+            return ctr
+
+        scale = icam.pixel_samples_scale
+        stats, (begin, count) = mg.render_frame(render_accumulate, accum, rank, world, SPP, scale=lambda a: a.mul_(scale))
+        rays = torch.tensor([float(stats.rays if stats is not None else 0), float(count)], dtype=torch.float64)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            np.savez(out_path, image=accum.numpy(), rays=rays.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_spp_split_and_reduce_matches_single_rank(tmp_path, world):
+    from oracle import pyoracle as po
+
+    out = str(tmp_path / "rank0.npz")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+
+    surfaces, cam = _scene()
+    sc = po.Scene(surfaces)
+    icam = po.camera_initialize(cam)
+    whole, ctr = sc.render(icam, SEED, 0, SPP, n_threads=1, iterative=True)
+    want = whole * icam.pixel_samples_scale
+    # same radiance values, summed in a different order
+    np.testing.assert_allclose(got["image"], want, rtol=1e-13, atol=1e-15)
+    assert got["image"].max() > 0.0
+    # every sample index was rendered exactly once, and the ray count is additive
+    assert int(got["rays"][1]) == SPP
+    assert int(got["rays"][0]) == ctr.rays
+
+
+def test_spp_range_partitions():
+    from raytracing_amd.multi_gpu import spp_range
+
+    assert [spp_range(r, 8, 500)[1] for r in range(8)] == [63, 63, 63, 63, 62, 62, 62, 62]
+    assert [spp_range(r, 8, 20000) for r in range(8)] == [(2500 * r, 2500) for r in range(8)]
+    for spp in (0, 1, 5, 500, 1000, 20000):
+        for world in (1, 2, 3, 4, 8, 16):
+            covered = []
+            for r in range(world):
+                b, c = spp_range(r, world, spp)
+                covered.extend(range(b, b + c))
+            assert covered == list(range(spp))
+            counts = [spp_range(r, world, spp)[1] for r in range(world)]
+            assert max(counts) - min(counts) <= 1
+    with pytest.raises(ValueError):
+        spp_range(2, 2, 10)
+
+
+def test_more_ranks_than_samples(tmp_path):
+    """Ranks with an empty sample range still join the reduce."""
+    from raytracing_amd.multi_gpu import spp_range
+
+    assert [spp_range(r, 4, 2) for r in range(4)] == [(0, 1), (1, 1), (2, 0), (2, 0)]
+
+
+def test_reduce_rejects_non_f64():
+    from raytracing_amd.multi_gpu import reduce_accum
+
+    with pytest.raises(TypeError):
+        reduce_accum(torch.zeros(4, dtype=torch.float32), 1)

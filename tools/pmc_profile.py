@@ -22,6 +22,8 @@ PASSES = [
     ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TA_BUSY_avr", "GRBM_GUI_ACTIVE"],
     ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_ATOMIC_sum", "TA_TA_BUSY_sum", "TA_FLAT_READ_WAVEFRONTS_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum"],
     ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum", "TCC_REQ_sum", "TCP_TOTAL_ACCESSES_sum", "TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum"],
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE"],
 ]
 
 
@@ -66,6 +68,20 @@ def main():
         for c in ctr_names:
             fh.write(f"| {c} | " + " | ".join(f"{summary[k].get(c, 0):.4g}" for k in keep) + " |\n")
     print(open(os.path.join(out, "pmc_summary.md")).read())
+    # HBM traffic per launch.  FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies 128-byte
+    # read requests as 64 bytes, so reads are doubled (an upper bound where narrower requests are mixed in).
+    traffic = {}
+    for k in keep:
+        n = summary[k].get("dispatches", 0)
+        if n and "FETCH_SIZE" in summary[k] and "WRITE_SIZE" in summary[k]:
+            rd = 2.0 * summary[k]["FETCH_SIZE"] * 1024.0 / n
+            wr = summary[k]["WRITE_SIZE"] * 1024.0 / n
+            traffic[k] = {"hbm_bytes_per_launch": round(rd + wr, 1), "read_bytes_per_launch": round(rd, 1),
+                          "write_bytes_per_launch": round(wr, 1), "launches": n,
+                          "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python3 bench.py " + " ".join(bench_args)}
+    with open(os.path.join(out, "hbm_traffic.json"), "w") as fh:
+        json.dump({"kernels": traffic}, fh, indent=1, sort_keys=True)
+    print(json.dumps(traffic, indent=1))
 
 
 if __name__ == "__main__":
