@@ -101,11 +101,12 @@ typedef struct rtx_stats {
     uint64_t node_visits;    /* box tests (0 unless counting was requested) */
     uint64_t sphere_tests;
     uint64_t planar_tests;
-    uint64_t iterations;     /* traverse+shade rounds launched */
+    uint64_t box_fallbacks;  /* box tests the single-precision tier left to the f64 tiers (counted with node_visits) */
+    uint64_t iterations;     /* generate+traverse+shade rounds launched, over all lanes */
     double   ms_total;       /* device time of the call, HIP events */
-    double   ms_traverse;    /* summed duration of the traverse kernel launches (0 unless RTX_FLAG_TIME_KERNELS) */
-    double   ms_shade;
-    double   ms_generate;    /* generate kernel launches plus the host's termination polls */
+    double   ms_traverse;    /* summed duration of the traverse kernel launches (0 unless RTX_FLAG_TIME_KERNELS). */
+    double   ms_shade;       /* A render call runs several independent lanes side by side on their own streams, */
+    double   ms_generate;    /* so kernels of different lanes overlap and these sums can exceed ms_total.       */
 } rtx_stats;
 
 typedef struct rtx_scene rtx_scene;
@@ -171,7 +172,8 @@ int rtx_render(rtx_scene* scene, const rtx_camera* cam, uint64_t seed, uint32_t 
 
 /* Device arithmetic self-test hooks used by the parity tests:
  * op 0: out[i] = a[i] / b[i]; op 1: out[i] = sqrt(a[i]);
- * op 2: out[i] = filtered-quotient of a[i], b[i] as the box test computes it. */
+ * op 2: out[i] = filtered-quotient of a[i], b[i] as the box test computes it;
+ * op 3: out[i] = (float)a[i] / (float)b[i] in single precision. */
 int rtx_selftest_math(int op, const double* a, const double* b, uint64_t n, double* out);
 
 /* Philox4x32-10 uniform doubles of stream (seed, pixel, sample) computed on the device. */

@@ -84,7 +84,7 @@ class CameraConfig(C.Structure):  # rtx_camera_config == struct Camera
 class Stats(C.Structure):  # rtx_stats
     _fields_ = [
         ("rays", C.c_uint64), ("paths", C.c_uint64), ("node_visits", C.c_uint64), ("sphere_tests", C.c_uint64),
-        ("planar_tests", C.c_uint64), ("iterations", C.c_uint64), ("ms_total", C.c_double), ("ms_traverse", C.c_double),
+        ("planar_tests", C.c_uint64), ("box_fallbacks", C.c_uint64), ("iterations", C.c_uint64), ("ms_total", C.c_double), ("ms_traverse", C.c_double),
         ("ms_shade", C.c_double), ("ms_generate", C.c_double),
     ]
 

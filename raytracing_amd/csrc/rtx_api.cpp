@@ -7,7 +7,9 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -64,35 +66,50 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 
 }  // namespace
 
-struct rtx_scene {
-    int device = 0;
-    uint32_t n_cus = 256;
-    DScene d{};
-    DevBuf<DNode> nodes;
-    DevBuf<DSphere> spheres;
-    DevBuf<DPlanar> planars;
-    DevBuf<DPrimInfo> prims;
-    DevBuf<DMaterial> materials;
-    DevBuf<DNode32> nodes32;
-    DevBuf<DBox64> boxes64;
-    DevBuf<uint32_t> sphere_prim, planar_prim;
-    bool f32_ok = false;   // every box plane is small enough for the single-precision tier
-    // path state (two buffers, ping-pong) and hit records, sized on first use and kept
+// One lane of the render loop: a path pool (two ping-pong state buffers and
+// the hit records), its control block and per-sub-pool counters, and the
+// stream its rounds run on.  Lanes are independent; a render call runs
+// several of them side by side so that one lane's closest-hit kernel (bound
+// by VALU issue) overlaps another lane's shade kernel (bound by memory latency).
+struct PathPool {
     size_t capacity = 0;
     DevBuf<double> buf_f64;     // 2 x 9 state arrays + hit_t
     DevBuf<uint32_t> buf_u32;   // 2 x 4 state arrays + hit_prim
     DevBuf<DRenderCtl> ctl;
+    DevBuf<uint32_t> counters;  // per sub-pool: live, survivors[0], survivors[1]
+    uint32_t counters_n = 0;
     DState state[2]{};
     DHits hits{};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr;            // owned
+    hipEvent_t ev_poll[2] = {nullptr, nullptr}, ev_done = nullptr;
+    uint32_t* h_poll = nullptr;              // two pinned words the host polls for the end of the lane's work
     std::vector<hipEvent_t> kernel_events;   // reused by RTX_FLAG_TIME_KERNELS, 3 per round
-    uint32_t* h_count = nullptr;             // pinned word the render loop polls
 
+    ~PathPool() {
+        for (hipEvent_t e : kernel_events) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_poll) if (e) (void)hipEventDestroy(e);
+        if (ev_done) (void)hipEventDestroy(ev_done);
+        if (h_poll) (void)hipHostFree(h_poll);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    int ensure_host_side() {
+        if (!stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (hipEvent_t& e : ev_poll) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (!ev_done) HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+        if (!h_poll) HIP_TRY(hipHostMalloc((void**)&h_poll, 2 * sizeof(uint32_t), hipHostMallocDefault));
+        return RTX_OK;
+    }
+    int ensure_counters(uint32_t n_sub) {
+        if (n_sub <= counters_n) return RTX_OK;
+        HIP_TRY(counters.resize(3 * (size_t)n_sub));
+        counters_n = n_sub;
+        return RTX_OK;
+    }
     int ensure_capacity(size_t n) {
+        HIP_TRY(ctl.resize(1));
         if (n <= capacity) return RTX_OK;
         HIP_TRY(buf_f64.resize(19 * n));
         HIP_TRY(buf_u32.resize(9 * n));
-        HIP_TRY(ctl.resize(1));
         double* f = buf_f64.p;
         uint32_t* u = buf_u32.p;
         for (int b = 0; b < 2; ++b) {
@@ -110,6 +127,30 @@ struct rtx_scene {
     }
 };
 
+struct rtx_scene {
+    int device = 0;
+    uint32_t n_cus = 256;
+    DScene d{};
+    DevBuf<DNode> nodes;
+    DevBuf<DSphere> spheres;
+    DevBuf<DPlanar> planars;
+    DevBuf<DPrimInfo> prims;
+    DevBuf<DMaterial> materials;
+    DevBuf<DNode32> nodes32;
+    DevBuf<DBox64> boxes64;
+    DevBuf<uint32_t> sphere_prim, planar_prim;
+    DevBuf<DShadeRec> shade_recs;
+    bool f32_ok = false;   // every box plane is small enough for the single-precision tier
+    // Lanes of the render loop, created on first use and kept.  Lane 0 also serves rtx_trace_closest.
+    std::vector<std::unique_ptr<PathPool>> lanes;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    PathPool* lane(size_t j) {
+        while (lanes.size() <= j) lanes.emplace_back(new PathPool());
+        return lanes[j].get();
+    }
+};
+
 extern "C" {
 
 const char* rtx_last_error(void) { return g_err.c_str(); }
@@ -124,6 +165,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     if (!desc || !out) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: null argument");
     *out = nullptr;
     const uint32_t n = desc->n_nodes, m = desc->n_prims, k = desc->n_materials;
+    if (n >= (1u << 27)) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: more than 2^27 - 1 nodes");
     if (n && (!desc->node_bmin || !desc->node_bmax || !desc->node_right || !desc->node_prim))
         return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: null node table");
     if (m && (!desc->prim_kind || !desc->prim_q || !desc->prim_material || !desc->prim_user_id))
@@ -180,8 +222,25 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     std::vector<DNode> nodes(n);
     std::vector<DNode32> nodes32(n);
     std::vector<DBox64> boxes64(n);
-    std::vector<uint32_t> sphere_prim, planar_prim;
-    for (uint32_t i = 0; i < m; ++i) (prims[i].kind == RTX_SPHERE ? sphere_prim : planar_prim).push_back(i);
+    if (m > HANDLE_PRIM_MASK) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: more than 2^28 - 1 surfaces");
+    std::vector<uint32_t> sphere_prim, planar_prim, handle(m);
+    std::vector<DShadeRec> shade_recs(m);
+    for (uint32_t i = 0; i < m; ++i) {
+        const DMaterial& mt = mats[prims[i].material];
+        const bool planar = prims[i].kind != RTX_SPHERE;
+        handle[i] = make_handle(i, mt.kind, planar);
+        (planar ? planar_prim : sphere_prim).push_back(handle[i]);
+        DShadeRec& r = shade_recs[i];
+        if (planar) {
+            for (int a = 0; a < 3; ++a) r.a[a] = planars[prims[i].slot].norm[a];
+            r.s = 0.0;
+        } else {
+            for (int a = 0; a < 3; ++a) r.a[a] = spheres[prims[i].slot].c[a];
+            r.s = 1.0 / spheres[prims[i].slot].r;
+        }
+        for (int a = 0; a < 3; ++a) r.rgb[a] = mt.rgb[a];
+        r.param = mt.param;
+    }
     bool f32_ok = true;
     std::vector<uint32_t> miss(n, NONE);
     bool filter_ok = true;
@@ -207,7 +266,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
             if (prim >= m) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: node_prim out of range");
             if (right != RTX_NONE) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: leaf with a right child");
             if (miss[i] != i + 1) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: leaf subtree is not a single node");
-            nd.prim = prim;
+            nd.prim = handle[prim];
             nd.kind = prims[prim].kind;
             nd.slot = prims[prim].slot;
             if (nd.slot >= (1u << 30)) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: more than 2^30 surfaces of one kind");
@@ -222,7 +281,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
             miss[i + 1] = right;
             miss[right] = miss[i];
         }
-        nodes32[i].miss = nd.miss;
+        nodes32[i].miss = nd.miss * 32u;
     }
 
     rtx_scene* sc = new rtx_scene();
@@ -250,6 +309,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     UP(boxes64, boxes64);
     UP(sphere_prim, sphere_prim);
     UP(planar_prim, planar_prim);
+    UP(shade_recs, shade_recs);
 #undef UP
     sc->d.nodes = sc->nodes.p;
     sc->d.spheres = sc->spheres.p;
@@ -263,6 +323,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     sc->d.boxes64 = sc->boxes64.p;
     sc->d.sphere_prim = sc->sphere_prim.p;
     sc->d.planar_prim = sc->planar_prim.p;
+    sc->d.shade_recs = sc->shade_recs.p;
     sc->f32_ok = f32_ok && filter_ok;
     if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
         return bail(fail(RTX_ERR_HIP, "hipEventCreate failed"));
@@ -274,37 +335,47 @@ void rtx_scene_destroy(rtx_scene* sc) {
     if (!sc) return;
     if (sc->ev0) (void)hipEventDestroy(sc->ev0);
     if (sc->ev1) (void)hipEventDestroy(sc->ev1);
-    for (hipEvent_t e : sc->kernel_events) (void)hipEventDestroy(e);
-    if (sc->h_count) (void)hipHostFree(sc->h_count);
     delete sc;
+}
+
+// Splits `need` slots into one sub-pool per wave of the launch grid: at most
+// `max_waves` sub-pools (a multiple of the waves per block), each a multiple of 64 slots.
+static void pool_geometry(uint64_t need, uint32_t max_waves, uint32_t* n_sub, uint64_t* sub_capacity) {
+    uint64_t waves = (need + 63) / 64;
+    waves = (waves + 3) & ~3ull;
+    if (waves < 4) waves = 4;
+    if (waves > max_waves) waves = max_waves;
+    *n_sub = (uint32_t)waves;
+    *sub_capacity = (((need + waves - 1) / waves) + 63) & ~63ull;
 }
 
 // Which closest-hit kernel a call uses: the reference's division form when the
 // caller asks for it, else the tiered test with the f32 records in LDS (small
 // trees), from global memory (large trees), or the f64-only filter (scenes
 // whose box planes are too large for f32, or on request).
-static void run_traverse(rtx_scene* sc, const DState& rays, const uint32_t* count_ptr, uint64_t max_count, double tmin, double tmax,
-                         uint32_t flags, uint32_t max_blocks, hipStream_t s) {
+static void run_traverse(rtx_scene* sc, PathPool* pp, const DState& rays, const DPool& pool, double tmin, double tmax, uint32_t flags,
+                         hipStream_t s) {
     const bool count_work = (flags & RTX_FLAG_COUNT_WORK) != 0;
     const uint32_t lds_limit = env_u32("RTX_LDS_NODE_BYTES", 40u * 1024u);
     if (flags & RTX_FLAG_EXACT_DIVIDE) {
-        launch_traverse(sc->d, rays, sc->hits, count_ptr, max_count, tmin, tmax, sc->ctl.p, count_work, true, max_blocks, s);
+        launch_traverse(sc->d, rays, pp->hits, pool, tmin, tmax, pp->ctl.p, count_work, true, s);
     } else if ((flags & RTX_FLAG_F64_FILTER) || !sc->f32_ok) {
-        launch_traverse(sc->d, rays, sc->hits, count_ptr, max_count, tmin, tmax, sc->ctl.p, count_work, false, max_blocks, s);
+        launch_traverse(sc->d, rays, pp->hits, pool, tmin, tmax, pp->ctl.p, count_work, false, s);
     } else {
         const bool lds = !(flags & RTX_FLAG_NO_LDS) && (size_t)sc->d.n_nodes * sizeof(DNode32) <= lds_limit;
-        launch_traverse_f32(sc->d, rays, sc->hits, count_ptr, max_count, tmin, tmax, sc->ctl.p, count_work, lds, max_blocks, s);
+        launch_traverse_f32(sc->d, rays, pp->hits, pool, tmin, tmax, pp->ctl.p, count_work, lds, s);
     }
 }
 
-static int read_counters(rtx_scene* sc, hipStream_t s, rtx_stats* stats) {
+static int read_counters(PathPool* pp, hipStream_t s, rtx_stats* stats) {
     DRenderCtl h;
-    HIP_TRY(hipMemcpyAsync(&h, sc->ctl.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&h, pp->ctl.p, sizeof(h), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     stats->rays += h.rays;
     stats->node_visits += h.node_visits;
     stats->sphere_tests += h.sphere_tests;
     stats->planar_tests += h.planar_tests;
+    stats->box_fallbacks += h.box_fallbacks;
     return RTX_OK;
 }
 
@@ -315,7 +386,13 @@ int rtx_trace_closest(rtx_scene* sc, const double* org, const double* dir, uint6
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (n == 0) return RTX_OK;
     HIP_TRY(hipSetDevice(sc->device));
-    int rc = sc->ensure_capacity((size_t)n);
+    const uint32_t max_waves = sc->n_cus * env_u32("RTX_BLOCKS_PER_CU", 8) * 4u;
+    uint32_t n_sub;
+    uint64_t sub_capacity;
+    pool_geometry(n, max_waves, &n_sub, &sub_capacity);
+    if (sub_capacity * n_sub > 0xFFFFFFFFull) return fail(RTX_ERR_BAD_ARG, "rtx_trace_closest: batch too large");
+    PathPool* pp = sc->lane(0);
+    int rc = pp->ensure_capacity((size_t)n);
     if (rc != RTX_OK) return rc;
     hipStream_t s = nullptr;
     DevBuf<double> d_rays;
@@ -323,18 +400,19 @@ int rtx_trace_closest(rtx_scene* sc, const double* org, const double* dir, uint6
     HIP_TRY(hipMemcpyAsync(d_rays.p, org, 3 * n * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_rays.p + 3 * n, dir, 3 * n * sizeof(double), hipMemcpyHostToDevice, s));
     DRenderCtl h{};
-    h.count_live = (uint32_t)n;
+    h.live_total = (uint32_t)n;
     h.rays = n;
-    HIP_TRY(hipMemcpyAsync(sc->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
-    launch_rays_to_state(d_rays.p, d_rays.p + 3 * n, n, sc->state[0], s);
-    const uint32_t max_blocks = sc->n_cus * env_u32("RTX_BLOCKS_PER_CU", 8);
+    HIP_TRY(hipMemcpyAsync(pp->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    launch_rays_to_state(d_rays.p, d_rays.p + 3 * n, n, pp->state[0], s);
+    // the batch as it lies in the state buffer, cut into one piece per wave
+    const DPool pool{nullptr, n_sub, (uint32_t)sub_capacity, (uint32_t)n};
     HIP_TRY(hipEventRecord(sc->ev0, s));
-    run_traverse(sc, sc->state[0], &sc->ctl.p->count_live, n, tmin, tmax, flags, max_blocks, s);
+    run_traverse(sc, pp, pp->state[0], pool, tmin, tmax, flags, s);
     HIP_TRY(hipEventRecord(sc->ev1, s));
-    launch_user_ids(sc->d.prims, sc->hits.prim, n, s);
+    launch_user_ids(sc->d.prims, pp->hits.prim, n, s);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out_id, sc->hits.prim, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(out_t, sc->hits.t, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_id, pp->hits.prim, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_t, pp->hits.t, n * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (uint64_t i = 0; i < n; ++i)
         if (out_id[i] == RTX_NONE) out_t[i] = INFINITY;
@@ -344,7 +422,7 @@ int rtx_trace_closest(rtx_scene* sc, const double* org, const double* dir, uint6
         stats->ms_total = ms;
         stats->ms_traverse = ms;
         stats->iterations = 1;
-        rc = read_counters(sc, s, stats);
+        rc = read_counters(pp, s, stats);
         if (rc != RTX_OK) return rc;
     }
     return RTX_OK;
@@ -391,6 +469,23 @@ int rtx_primary_rays(const rtx_camera* cam, uint64_t seed, uint32_t sample, doub
     return RTX_OK;
 }
 
+namespace {
+
+// What one lane of a render call needs to enqueue a round.
+struct LaneRun {
+    PathPool* pp = nullptr;
+    DPool pool{};
+    uint32_t* live = nullptr;
+    uint32_t* surv[2] = {nullptr, nullptr};
+    uint32_t n_sub = 0, sub_capacity = 0;
+    uint64_t iters = 0;     // rounds enqueued
+    size_t n_evs = 0;       // kernel timing events used
+    uint32_t polls = 0;     // polls enqueued
+    bool done = false;
+};
+
+}  // namespace
+
 int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, uint32_t spp_begin, uint32_t spp_count,
                           uint32_t flags, double* d_accum, void* stream, rtx_stats* stats) {
     if (!sc || !d_accum) return fail(RTX_ERR_BAD_ARG, "rtx_render_accumulate: null argument");
@@ -404,89 +499,164 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     HIP_TRY(hipSetDevice(sc->device));
     hipStream_t s = (hipStream_t)stream;
 
+    // The paths of the call are cut into contiguous ranges, one per lane; every lane has its own
+    // pool of up to `want` slots (one slot per path for small calls), one sub-pool per wave of its launches.
     const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 22);
-    const uint32_t slots = (uint32_t)(total < want ? total : want);
-    rc = sc->ensure_capacity(slots);
-    if (rc != RTX_OK) return rc;
-    const uint32_t max_blocks = sc->n_cus * env_u32("RTX_BLOCKS_PER_CU", 8);
+    const uint32_t max_waves = sc->n_cus * env_u32("RTX_BLOCKS_PER_CU", 8) * 4u;
     const uint32_t check_every = env_u32("RTX_CHECK_EVERY", 4);
+    uint32_t n_lanes = env_u32("RTX_LANES", 2);
+    if (n_lanes > 8) n_lanes = 8;
+    while (n_lanes > 1 && total / n_lanes < (1u << 18)) --n_lanes;   // small calls: not worth splitting
     const bool time_kernels = (flags & RTX_FLAG_TIME_KERNELS) != 0;
     const DCamera dcam = to_dcamera(cam);
 
-    // Round r works on state buffer r & 1 (all on one stream, no host round trip inside a round):
-    //   generate : start new paths behind the survivors until the buffer is full
-    //   traverse : closest hit of every ray in the buffer
-    //   shade    : scatter / terminate; survivors are written densely into the other buffer
-    DRenderCtl h{};
-    h.total_paths = total;
-    HIP_TRY(hipMemcpyAsync(sc->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(sc->ev0, s));
-    DRenderCtl* ctl = sc->ctl.p;
+    std::vector<LaneRun> lanes(n_lanes);
+    for (uint32_t j = 0; j < n_lanes; ++j) {
+        LaneRun& L = lanes[j];
+        L.pp = sc->lane(j);
+        const uint64_t first = total * j / n_lanes, last = total * (j + 1) / n_lanes;
+        const uint64_t need = last - first < want ? last - first : want;
+        uint64_t per_sub;
+        pool_geometry(need, max_waves, &L.n_sub, &per_sub);
+        if (per_sub * L.n_sub > 0xFFFFFFFFull) return fail(RTX_ERR_BAD_ARG, "rtx_render_accumulate: pool larger than 2^32-1 slots");
+        L.sub_capacity = (uint32_t)per_sub;
+        rc = L.pp->ensure_host_side();
+        if (rc == RTX_OK) rc = L.pp->ensure_capacity((size_t)L.sub_capacity * L.n_sub);
+        if (rc == RTX_OK) rc = L.pp->ensure_counters(L.n_sub);
+        if (rc != RTX_OK) return rc;
+        L.live = L.pp->counters.p;
+        L.surv[0] = L.pp->counters.p + L.n_sub;
+        L.surv[1] = L.pp->counters.p + 2 * (size_t)L.n_sub;
+        L.pool = DPool{L.live, L.n_sub, L.sub_capacity, 0u};
+        hipStream_t ls = L.pp->stream;
+        HIP_TRY(hipStreamWaitEvent(ls, sc->ev0, 0));   // after whatever the caller queued on `stream`
+        DRenderCtl h{};
+        h.next_path[0] = first;
+        h.total_paths = last;
+        HIP_TRY(hipMemcpyAsync(L.pp->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, ls));
+        HIP_TRY(hipMemsetAsync(L.pp->counters.p, 0, 3 * (size_t)L.n_sub * sizeof(uint32_t), ls));
+        L.pp->h_poll[0] = L.pp->h_poll[1] = 1u;
+    }
 
-    std::vector<hipEvent_t>& evs = sc->kernel_events;   // only with RTX_FLAG_TIME_KERNELS: 3 per round
-    size_t n_evs = 0;
-    if (!sc->h_count) HIP_TRY(hipHostMalloc((void**)&sc->h_count, sizeof(uint32_t), hipHostMallocDefault));
-    uint32_t* h_count = sc->h_count;
-    *h_count = slots;
-    uint64_t iters = 0;
+    // One round of a lane works on its state buffer (round & 1), all on the lane's stream:
+    //   generate : start new paths behind the survivors until the sub-pools are full
+    //   traverse : closest hit of every ray in the pool
+    //   shade    : scatter / terminate; survivors are written densely into the other buffer
     int status = RTX_OK;
-    for (;;) {
-        const uint32_t cur = (uint32_t)(iters & 1u), nxt = cur ^ 1u;
-        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-        if (time_kernels) {
-            while (evs.size() < n_evs + 3) {
-                hipEvent_t e = nullptr;
-                if (hipEventCreate(&e) != hipSuccess) break;
-                evs.push_back(e);
+    auto enqueue_batch = [&](LaneRun& L) -> int {
+        PathPool* pp = L.pp;
+        hipStream_t ls = pp->stream;
+        DRenderCtl* ctl = pp->ctl.p;
+        for (uint32_t r = 0; r < check_every; ++r) {
+            const uint32_t cur = (uint32_t)(L.iters & 1u), nxt = cur ^ 1u;
+            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+            if (time_kernels) {
+                std::vector<hipEvent_t>& evs = pp->kernel_events;
+                while (evs.size() < L.n_evs + 4) {
+                    hipEvent_t e = nullptr;
+                    if (hipEventCreate(&e) != hipSuccess) return fail(RTX_ERR_HIP, "hipEventCreate failed");
+                    evs.push_back(e);
+                }
+                e0 = evs[L.n_evs]; e1 = evs[L.n_evs + 1]; e2 = evs[L.n_evs + 2]; e3 = evs[L.n_evs + 3];
+                L.n_evs += 4;
+                (void)hipEventRecord(e0, ls);
             }
-            if (evs.size() < n_evs + 3) {
-                status = fail(RTX_ERR_HIP, "hipEventCreate failed");
-                break;
+            launch_generate(dcam, pp->state[cur], ctl, L.surv[cur], L.live, L.n_sub, L.sub_capacity, cur, seed, spp_begin, ls);
+            if (time_kernels) (void)hipEventRecord(e1, ls);
+            run_traverse(sc, pp, pp->state[cur], L.pool, 0.001, INFINITY, flags, ls);   // Interval(0.001, inf), camera.rs:194
+            if (time_kernels) (void)hipEventRecord(e2, ls);
+            launch_shade(sc->d, dcam, pp->state[cur], pp->hits, L.pool, pp->state[nxt], L.surv[nxt], seed, d_accum, ls);
+            if (time_kernels) (void)hipEventRecord(e3, ls);
+#ifdef RTX_REPLAY
+            // Kernel A/B aid (never compiled into the product): at one steady-state
+            // round, re-run traverse and shade on the same input and print their times.
+            if (L.iters == env_u32("RTX_REPLAY_ROUND", 15)) {
+                const uint32_t reps = env_u32("RTX_REPLAY_REPS", 20);
+                hipEvent_t a, b, c;
+                (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventCreate(&c);
+                (void)hipEventRecord(a, ls);
+                for (uint32_t q = 0; q < reps; ++q) run_traverse(sc, pp, pp->state[cur], L.pool, 0.001, INFINITY, flags, ls);
+                (void)hipEventRecord(b, ls);
+                for (uint32_t q = 0; q < reps; ++q)
+                    launch_shade(sc->d, dcam, pp->state[cur], pp->hits, L.pool, pp->state[nxt], L.surv[nxt], seed, d_accum, ls);
+                (void)hipEventRecord(c, ls);
+                (void)hipStreamSynchronize(ls);
+                float t1 = 0.f, t2 = 0.f;
+                (void)hipEventElapsedTime(&t1, a, b);
+                (void)hipEventElapsedTime(&t2, b, c);
+                uint32_t n_live = 0;
+                (void)hipMemcpy(&n_live, &ctl->live_total, 4, hipMemcpyDeviceToHost);
+                std::fprintf(stderr, "REPLAY round %llu live %u: traverse %.1f us, shade %.1f us\n", (unsigned long long)L.iters, n_live,
+                             1e3 * t1 / reps, 1e3 * t2 / reps);
             }
-            e0 = evs[n_evs]; e1 = evs[n_evs + 1]; e2 = evs[n_evs + 2];
-            n_evs += 3;
+#endif
+            ++L.iters;
         }
-        launch_generate(dcam, sc->state[cur], slots, ctl, cur, seed, spp_begin, max_blocks, s);
-        if (time_kernels) (void)hipEventRecord(e0, s);
-        run_traverse(sc, sc->state[cur], &ctl->count_live, slots, 0.001, INFINITY, flags, max_blocks, s);   // Interval(0.001, inf), camera.rs:194
-        if (time_kernels) (void)hipEventRecord(e1, s);
-        launch_shade(sc->d, dcam, sc->state[cur], sc->hits, &ctl->count_live, sc->state[nxt], &ctl->count_surv[nxt], slots, seed,
-                     d_accum, max_blocks, s);
-        if (time_kernels) (void)hipEventRecord(e2, s);
-        ++iters;
-        if (iters % check_every == 0) {
-            // finished when a round had nothing to trace: no survivors and no paths left to start
-            hipError_t e = hipMemcpyAsync(h_count, &ctl->count_live, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
+        // a lane is finished when a round had nothing to trace: no survivors and no paths left to start
+        const uint32_t slot = L.polls & 1u;
+        hipError_t e = hipMemcpyAsync(pp->h_poll + slot, &ctl->live_total, sizeof(uint32_t), hipMemcpyDeviceToHost, ls);
+        if (e == hipSuccess) e = hipEventRecord(pp->ev_poll[slot], ls);
+        if (e != hipSuccess) return fail(RTX_ERR_HIP, std::string("render loop: ") + hipGetErrorString(e));
+        ++L.polls;
+        return RTX_OK;
+    };
+
+    // Two batches of rounds are kept in flight per lane, so a lane's stream does not run dry while the
+    // host waits for an older batch's poll; the rounds enqueued after a lane has finished find no work.
+    for (LaneRun& L : lanes)
+        for (int k = 0; k < 2 && status == RTX_OK; ++k) status = enqueue_batch(L);
+    uint32_t n_done = 0;
+    while (status == RTX_OK && n_done < n_lanes) {
+        for (LaneRun& L : lanes) {
+            if (L.done || status != RTX_OK) continue;
+            const uint32_t slot = L.polls & 1u;   // the older of the two polls in flight
+            hipError_t e = hipEventSynchronize(L.pp->ev_poll[slot]);
             if (e != hipSuccess) {
                 status = fail(RTX_ERR_HIP, std::string("render loop: ") + hipGetErrorString(e));
                 break;
             }
-            if (*h_count == 0) break;
+            if (L.pp->h_poll[slot] == 0u) {
+                L.done = true;
+                ++n_done;
+            } else {
+                status = enqueue_batch(L);
+            }
         }
+    }
+    // the caller's stream continues after every lane has drained
+    for (LaneRun& L : lanes) {
+        hipError_t e = hipEventRecord(L.pp->ev_done, L.pp->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, L.pp->ev_done, 0);
+        if (e != hipSuccess && status == RTX_OK) status = fail(RTX_ERR_HIP, std::string("render: ") + hipGetErrorString(e));
     }
     if (status == RTX_OK) {
         hipError_t e = hipEventRecord(sc->ev1, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) status = fail(RTX_ERR_HIP, std::string("render: ") + hipGetErrorString(e));
+    } else {
+        for (LaneRun& L : lanes) (void)hipStreamSynchronize(L.pp->stream);
     }
     if (status == RTX_OK && stats) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, sc->ev0, sc->ev1);
         stats->ms_total = ms;
         stats->paths = total;
-        stats->iterations = iters;
-        for (size_t i = 0; i + 2 < n_evs; i += 3) {
-            float a = 0.f, b = 0.f, g = 0.f;
-            (void)hipEventElapsedTime(&a, evs[i], evs[i + 1]);
-            (void)hipEventElapsedTime(&b, evs[i + 1], evs[i + 2]);
-            (void)hipEventElapsedTime(&g, i == 0 ? sc->ev0 : evs[i - 1], evs[i]);   // includes the host's poll every few rounds
-            stats->ms_traverse += a;
-            stats->ms_shade += b;
-            stats->ms_generate += g;
+        for (LaneRun& L : lanes) {
+            stats->iterations += L.iters;
+            const std::vector<hipEvent_t>& evs = L.pp->kernel_events;
+            for (size_t i = 0; i + 3 < L.n_evs; i += 4) {
+                float g = 0.f, a = 0.f, b = 0.f;
+                (void)hipEventElapsedTime(&g, evs[i], evs[i + 1]);
+                (void)hipEventElapsedTime(&a, evs[i + 1], evs[i + 2]);
+                (void)hipEventElapsedTime(&b, evs[i + 2], evs[i + 3]);
+                stats->ms_generate += g;
+                stats->ms_traverse += a;
+                stats->ms_shade += b;
+            }
+            if (status == RTX_OK) status = read_counters(L.pp, L.pp->stream, stats);
         }
-        status = read_counters(sc, s, stats);
     }
     return status;
 }

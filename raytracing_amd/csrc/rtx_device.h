@@ -7,6 +7,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <stdint.h>
 
 namespace rtx {
@@ -35,7 +36,7 @@ static_assert(sizeof(DNode) == 64, "node record must be one 64-byte line");
 // 16-byte loads per visit, half of the f64 record.
 struct __attribute__((aligned(32))) DNode32 {
     float plane[6];   // lo.x, hi.x, lo.y, hi.y, lo.z, hi.z
-    uint32_t miss;    // as DNode::miss
+    uint32_t miss;    // DNode::miss as the byte offset of that node's record (index * 32)
     uint32_t leaf;    // NONE for an internal node, else (geometry kind << 30) | slot
 };
 static_assert(sizeof(DNode32) == 32, "f32 node record must be 32 bytes");
@@ -62,6 +63,25 @@ struct DMaterial {                              // enum Material, src/material.r
     uint32_t kind;
     uint32_t _pad;
 };
+// Everything the shade kernel needs about the surface that won, in one
+// 64-byte record per prim so it arrives with one dependent round trip:
+//   sphere: a = center, s = 1.0 / radius  (`(p - c) / r` is `(p - c) * (1.0 / r)`, src/vector.rs:179-190)
+//   planar: a = norm,   s unused
+// plus the material's colour and parameter.  Geometry and material KIND do not
+// need a load at all: they travel in the hit handle.
+struct DShadeRec {
+    double a[3];
+    double s;
+    double rgb[3];
+    double param;
+};
+// Hit handle written by the closest-hit kernels: prim index in the low 28
+// bits, material kind in bits 28-30, bit 31 set for planar geometry.  NONE
+// (all ones) cannot collide: material kinds stop at 4.
+constexpr uint32_t HANDLE_PRIM_MASK = 0x0FFFFFFFu;
+__host__ __device__ inline uint32_t make_handle(uint32_t prim, uint32_t mat_kind, bool planar) {
+    return prim | (mat_kind << 28) | (planar ? 0x80000000u : 0u);
+}
 
 struct DScene {
     const DNode* nodes;
@@ -74,8 +94,9 @@ struct DScene {
     uint32_t filter_ok;   // every box coordinate is finite and small enough for the filtered box test
     const DNode32* nodes32;
     const DBox64* boxes64;
-    const uint32_t* sphere_prim;   // slot in the sphere table -> prim index
-    const uint32_t* planar_prim;   // slot in the planar table -> prim index
+    const uint32_t* sphere_prim;   // slot in the sphere table -> hit handle of that prim
+    const uint32_t* planar_prim;   // slot in the planar table -> hit handle of that prim
+    const DShadeRec* shade_recs;   // per prim
 };
 
 // State of the paths in flight, struct-of-arrays.  Entry i of every array
@@ -90,7 +111,7 @@ struct DState {
 };
 // Closest-hit record of ray i of the current round.
 struct DHits {
-    uint32_t* prim;
+    uint32_t* prim;   // hit handle (make_handle) or NONE
     double* t;
 };
 
@@ -101,6 +122,23 @@ struct DCamera {   // InitializedCamera, src/camera.rs:28-43
     double center[3], pixel00_loc[3], pixel_du[3], pixel_dv[3], defocus_disk_u[3], defocus_disk_v[3];
 };
 
+// The path pool is split into one private sub-pool per wave of the (fixed)
+// launch grid: wave w of every kernel works on slots
+// [w * sub_capacity, w * sub_capacity + counts[w]).  A wave compacts its own
+// survivors into its own sub-pool of the other buffer, in order, so no two
+// waves ever write the same counter or reserve slots from a shared one: the
+// round loop has no atomics besides the radiance accumulation.  (A returning
+// atomic on a single address sustains fewer than 100 operations per
+// microsecond on this part; shared counters throttled every earlier layout.)
+// Order-preserving compaction also keeps rays that started at neighbouring
+// pixels next to each other, which the closest-hit kernel rewards.
+struct DPool {
+    const uint32_t* counts;   // rays per sub-pool; nullptr: one flat batch of flat_total rays cut into sub_capacity pieces
+    uint32_t n_sub;           // == number of waves of every launch on this pool
+    uint32_t sub_capacity;    // multiple of 64
+    uint32_t flat_total;
+};
+
 // Control block of one render call (device memory).  Words that one kernel
 // reads while another word of the same meaning is written are kept twice,
 // indexed by round parity.
@@ -109,9 +147,9 @@ struct DRenderCtl {
     unsigned long long total_paths;
     unsigned long long rays;           // closest-hit queries issued so far
     unsigned long long node_visits, sphere_tests, planar_tests;
-    uint32_t count_live;               // rays of the current round
-    uint32_t count_surv[2];            // survivors written into state buffer [parity]
-    uint32_t next_ray;                 // work counter of the traverse kernel
+    unsigned long long box_fallbacks;  // box tests the f32 tier left undecided
+    uint32_t live_total;               // rays of the current round over all sub-pools (the host polls this)
+    uint32_t _pad;
 };
 
 // ---------------------------------------------------------------- Vector3 (src/vector.rs)
@@ -323,75 +361,73 @@ __device__ __forceinline__ bool filter_ray_ok(V3 o, V3 d, double tmin, double tm
 }
 
 // ---------------------------------------------------------------- f32 first tier
-// The same three comparisons (hi* > tmin, lo* < tmax, lo* < hi*), first tried
-// in single precision.  With b32 = RN32(b), inv32 = RN32(RN64(1/d)),
-// oi32 = RN32(RN64(-o * RN64(1/d))) the slab distance t~ = b32*inv32 + oi32,
-// evaluated in f32 with or without fusing, differs from the real quotient
-// (b - o)/d by at most
-//     2^-24 * (3|b/d| + |o/d| + |t~|) * (1 + 2^-20)
-// (one rounding each for b32, inv32, oi32, the product and the sum; the f64
-// roundings behind inv and oi are 2^-29 times smaller).  With
-// |b/d| <= mag*|inv32|(1 + 2^-23), mag = the larger plane magnitude of the
-// axis, and |t~| <= |b32*inv32| + |oi32|, this is below
-//     e_axis = mag * A_axis + B_axis,  A = 4.04 * 2^-24 * |inv32|,  B = 2.02 * 2^-24 * |oi32|,
-// and max/min over the axes move lo and hi by at most E = max_axis e_axis.
-// The reference's own f64 rounding of each quotient (2^-53 relative) is
-// inside the 1 % slack of the constants.  A comparison is accepted only if
-// it holds with E (and a 2^-20 relative guard on tmin/tmax for the f32
-// rounding of the subtraction) to spare; anything else, including any NaN or
-// infinity produced on the way, leaves the visit undecided and it is
-// repeated in f64.  To keep every f32 operation inside the normal range
-// (where the 2^-24 relative rounding model holds, and no NaN or infinity can
-// arise that min/max would silently drop) a ray takes this tier only if
-// 1e-30 <= |inv32| <= 1e15 and |oi32| <= 1e15 on every axis with oi32 either
-// zero or at least 1e-30, and a scene only if every box plane is at most
-// 1e15 in magnitude; the absolute term 1e-30 in B covers planes so small that
-// their f32 copy is subnormal.
+// The same predicate (hi* > tmin, lo* < tmax, lo* < hi*), first tried in
+// single precision.  Write u = 2^-24.  With
+//     b32 = RN32(b),  inv32 = RN32(1 / RN32(d)),  oi32 = RN32(RN32(o) * inv32)
+// (so inv32 = (1/d)(1 + di), |di| <= 2.001u, and oi32 = (o/d)(1 + do)(1 + di)(1 + dm)),
+// the slab distance t~ = RN32(b32 * inv32 - oi32), one fused operation, satisfies
+//     |t~ - Q| <= |Q| 3.002u + |b/d| 1.001u + |o/d| 2.002u,        Q = (b - o)/d,
+// and with |b/d| <= |Q| + |o/d|, |Q| <= |t~| + |t~ - Q|, |o/d| <= |oi32|(1 + 3.01u):
+//     |t~ - Q| <= 4.01u (|t~| + |oi32|).
+// The reference's own quotient is RN64 of the difference over d, within
+// 2^-52 |Q| of Q.  So with M >= every |t~| of the node and OI >= every |oi32|
+// of the ray, max/min over the axes move lo and hi by at most
+//     E = 4.05u (M + OI) + 1e-30
+// (the absolute term covers planes and products below the f32 normal range).
+// Let s1 = hi - tmin32, s2 = tmax32 - lo, s3 = hi - lo in f32 and m their
+// minimum.  Rounding tmin, tmax to f32 and the subtractions cost at most
+// 2^-22 max(tmin, tmax) more, so with M' = max(M, tg), tg = tmax32 if finite
+// else tmin32, and
+//     T = 12.2u M' + (8.1u OI + 2e-30)   >=   2E + 2^-22 tg (1 + small),
+// m > T proves the predicate true and m < -T proves it false (some s_k is then
+// negative beyond its error).  Anything else, including any NaN or infinity
+// on the way, leaves the visit undecided and it is repeated in f64.  To keep
+// every f32 operation finite and the rounding model valid, a ray takes this
+// tier only if 1e-30 <= |inv32| <= 1e15 and |oi32| <= 1e15 on every axis and
+// 1e-30 <= tmin <= 1e15, and a scene only if every box plane is at most 1e15
+// in magnitude; otherwise K is +infinity and every visit is undecided.
 struct RayF32 {
-    float inv[3], oi[3], A[3], B[3];
-    float tmin_up, tmin_dn, tmax_up, tmax_dn;
+    float inv[3], oi[3];   // oi holds +o/d: t~ = fma(b32, inv, -oi)
+    float K;               // 8.1u * OI + 2e-30, or +inf when the ray skips this tier
+    float tmin32, tmax32, tg;
 };
 __device__ __forceinline__ void rayf32_set_tmax(RayF32& r, double tmax) {
     const float t = (float)tmax;
-    r.tmax_up = t * (1.0f + 0x1.0p-20f);
-    r.tmax_dn = t * (1.0f - 0x1.0p-20f);
+    r.tmax32 = t;
+    r.tg = t <= 3.0e38f ? t : r.tmin32;   // tmax >= tmin always
 }
-// returns false when the ray must skip the f32 tier
-__device__ __forceinline__ bool rayf32_init(RayF32& r, V3 o, V3 inv, double tmin, double tmax) {
-    const double iv[3] = {inv.x, inv.y, inv.z};
-    const double ov[3] = {o.x, o.y, o.z};
+__device__ __forceinline__ void rayf32_init(RayF32& r, V3 o, V3 d, double tmin, double tmax) {
+    const float dv[3] = {(float)d.x, (float)d.y, (float)d.z};
+    const float ov[3] = {(float)o.x, (float)o.y, (float)o.z};
     bool ok = true;
+    float oi_max = 0.0f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        r.inv[a] = (float)iv[a];
-        r.oi[a] = (float)(-ov[a] * iv[a]);
+        r.inv[a] = 1.0f / dv[a];            // correctly rounded (no fast-math)
+        r.oi[a] = ov[a] * r.inv[a];
         const float ai = fabsf(r.inv[a]), ao = fabsf(r.oi[a]);
-        ok = ok && ai >= 1e-30f && ai <= 1e15f && ao <= 1e15f && (ao == 0.0f || ao >= 1e-30f);
-        r.A[a] = ai * (4.04f * 0x1.0p-24f);
-        r.B[a] = ao * (2.02f * 0x1.0p-24f) + 1e-30f;
+        ok = ok && ai >= 1e-30f && ai <= 1e15f && ao <= 1e15f;   // NaN fails every comparison
+        oi_max = fmaxf(oi_max, ao);
     }
     const float t = (float)tmin;
-    r.tmin_up = t * (1.0f + 0x1.0p-20f);
-    r.tmin_dn = t * (1.0f - 0x1.0p-20f);
+    ok = ok && t >= 1e-30f && t <= 1e15f;
+    r.tmin32 = t;
+    r.K = ok ? oi_max * (8.1f * 0x1.0p-24f) + 2e-30f : __builtin_inff();
     rayf32_set_tmax(r, tmax);
-    return ok && t >= 1e-30f && t <= 1e15f;
 }
 // 1 = hit for certain, 0 = miss for certain, -1 = undecided
 __device__ __forceinline__ int box_hit_f32(const float p[6], const RayF32& r) {
-    const float t0x = fmaf(p[0], r.inv[0], r.oi[0]), t1x = fmaf(p[1], r.inv[0], r.oi[0]);
-    const float t0y = fmaf(p[2], r.inv[1], r.oi[1]), t1y = fmaf(p[3], r.inv[1], r.oi[1]);
-    const float t0z = fmaf(p[4], r.inv[2], r.oi[2]), t1z = fmaf(p[5], r.inv[2], r.oi[2]);
-    // larger plane magnitude of an axis: lo <= hi, so max(|lo|, |hi|) = max(-lo, hi)
-    const float ex = fmaf(fmaxf(-p[0], p[1]), r.A[0], r.B[0]);
-    const float ey = fmaf(fmaxf(-p[2], p[3]), r.A[1], r.B[1]);
-    const float ez = fmaf(fmaxf(-p[4], p[5]), r.A[2], r.B[2]);
-    const float E = fmaxf(fmaxf(ex, ey), ez) * 1.001f;
-    const float lo = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-    const float hi = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-    const float E2 = E + E;
-    const bool hit = (hi - E > r.tmin_up) && (lo + E < r.tmax_dn) && (hi - lo > E2);
-    const bool miss = (hi + E < r.tmin_dn) || (lo - E > r.tmax_up) || (lo - hi > E2);
-    return hit ? 1 : (miss ? 0 : -1);
+    const float t0x = fmaf(p[0], r.inv[0], -r.oi[0]), t1x = fmaf(p[1], r.inv[0], -r.oi[0]);
+    const float t0y = fmaf(p[2], r.inv[1], -r.oi[1]), t1y = fmaf(p[3], r.inv[1], -r.oi[1]);
+    const float t0z = fmaf(p[4], r.inv[2], -r.oi[2]), t1z = fmaf(p[5], r.inv[2], -r.oi[2]);
+    const float nx = fminf(t0x, t1x), ny = fminf(t0y, t1y), nz = fminf(t0z, t1z);
+    const float fx = fmaxf(t0x, t1x), fy = fmaxf(t0y, t1y), fz = fmaxf(t0z, t1z);
+    const float lo = fmaxf(fmaxf(nx, ny), nz), hi = fminf(fminf(fx, fy), fz);
+    const float mn = fminf(fminf(nx, ny), nz), mx = fmaxf(fmaxf(fx, fy), fz);
+    const float M = fmaxf(fmaxf(-mn, mx), r.tg);
+    const float T = fmaf(M, 12.2f * 0x1.0p-24f, r.K);
+    const float m = fminf(fminf(hi - r.tmin32, r.tmax32 - lo), hi - lo);
+    return m > T ? 1 : (m < -T ? 0 : -1);
 }
 
 // ---------------------------------------------------------------- primitive tests

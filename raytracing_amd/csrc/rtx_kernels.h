@@ -4,19 +4,17 @@
 
 namespace rtx {
 
-void launch_generate(const DCamera& cam, const DState& st, uint32_t capacity, DRenderCtl* ctl, uint32_t parity, uint64_t seed,
-                     uint32_t spp_begin, uint32_t max_blocks, hipStream_t s);
+void launch_generate(const DCamera& cam, const DState& st, DRenderCtl* ctl, const uint32_t* surv, uint32_t* live, uint32_t n_sub,
+                     uint32_t sub_capacity, uint32_t parity, uint64_t seed, uint32_t spp_begin, hipStream_t s);
 void launch_primary_rays(const DCamera& cam, uint64_t seed, uint32_t sample, uint32_t npix, double* org, double* dir,
                          uint32_t max_blocks, hipStream_t s);
-void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, const uint32_t* count_ptr,
-                     uint64_t max_count, double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool exact,
-                     uint32_t max_blocks, hipStream_t s);
-void launch_traverse_f32(const DScene& sc, const DState& rays, const DHits& hits, const uint32_t* count_ptr, uint64_t max_count,
-                         double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool lds_nodes, uint32_t max_blocks,
-                         hipStream_t s);
-void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const uint32_t* count_in,
-                  const DState& nxt, uint32_t* count_out, uint64_t max_count, uint64_t seed, double* accum, uint32_t max_blocks,
-                  hipStream_t s);
+// The pool kernels run one wave per sub-pool of `pool`.
+void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, const DPool& pool, double tmin, double tmax,
+                     DRenderCtl* ctl, bool count_work, bool exact, hipStream_t s);
+void launch_traverse_f32(const DScene& sc, const DState& rays, const DHits& hits, const DPool& pool, double tmin, double tmax,
+                         DRenderCtl* ctl, bool count_work, bool lds_nodes, hipStream_t s);
+void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const DPool& pool, const DState& nxt,
+                  uint32_t* counts_out, uint64_t seed, double* accum, hipStream_t s);
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s);
 void launch_quantize(const double* in, uint64_t n, uint8_t* out, hipStream_t s);
 void launch_rays_to_state(const double* org, const double* dir, uint64_t n, const DState& st, hipStream_t s);

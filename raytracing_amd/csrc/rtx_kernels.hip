@@ -1,13 +1,15 @@
 // rtx_kernels.hip -- gfx950 kernels of the wavefront path tracer.
 //
 // One round of the render loop is three launches on one stream:
-//   k_generate   start new paths (sample_square + get_ray) behind the
-//                survivors of the previous round, filling the state buffer
-//   k_traverse   closest hit of every live ray over the threaded pre-order
-//                BVH (BVH::hit); persistent waves that refill idle lanes
-//   k_shade      complete the hit, emitted + scatter, accumulate finished
-//                paths, and write the surviving paths densely into the other
-//                state buffer (64-wide ballot + prefix count, one atomic per wave)
+//   k_generate      start new paths (sample_square + get_ray) behind the
+//                   survivors of the previous round until every sub-pool is full
+//   k_traverse_f32  closest hit of every live ray over the threaded pre-order
+//   / k_traverse    BVH (BVH::hit)
+//   k_shade         complete the hit, emitted + scatter, accumulate finished
+//                   paths, and write the surviving paths densely and in order
+//                   into the other state buffer (64-wide ballot + prefix count)
+// Every wave of a launch owns one sub-pool of the path pool (DPool): the
+// three kernels use the same grid, and nothing is shared between waves.
 // k_scale / k_quantize are the output stage.
 //
 // Citations "file:line" are into the reference repository.
@@ -37,6 +39,30 @@ constexpr int BLOCK = 256;
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 __device__ __forceinline__ uint32_t rank_below(unsigned long long mask, uint32_t lane) {
     return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// The sub-pool of this wave: its index, ray count and first slot (wave-uniform).
+struct WaveSlot {
+    uint32_t sub, count, base;
+};
+__device__ __forceinline__ WaveSlot wave_slot(const DPool& pool) {
+    WaveSlot w;
+    w.sub = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
+    w.base = w.sub * pool.sub_capacity;
+    if (w.sub >= pool.n_sub) {
+        w.count = 0u;
+    } else if (pool.counts) {
+        w.count = pool.counts[w.sub];
+    } else {
+        const uint32_t rest = pool.flat_total > w.base ? pool.flat_total - w.base : 0u;
+        w.count = rest < pool.sub_capacity ? rest : pool.sub_capacity;
+    }
+    return w;
+}
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
 // ---------------------------------------------------------------- primary rays
@@ -77,33 +103,85 @@ __device__ __forceinline__ void split_path_index(unsigned long long g, unsigned 
     pixel = (uint32_t)(g - q * npix);
 }
 
-// Appends new paths behind the survivors in state buffer `st` until the
-// buffer is full or every path of the call has been started, and publishes
-// the round's ray count.  Thread 0 also resets the counters that the
-// following traverse and shade kernels bump.
-__global__ __launch_bounds__(BLOCK) void k_generate(DCamera cam, DState st, uint32_t capacity, DRenderCtl* ctl, uint32_t parity,
-                                                    uint64_t seed, uint32_t spp_begin) {
-    const uint32_t n_surv = ctl->count_surv[parity];
+// Appends new paths behind the survivors of every sub-pool of state buffer
+// `st` until the sub-pool is full or every path of the call has been started,
+// and publishes the round's ray counts.  Sub-pool s takes the path indices
+// that follow those of sub-pools 0..s-1, so each block first sums what the
+// sub-pools before its own will start (plain loads, no communication between
+// blocks).  When fewer paths are left than there is room, they are shared out
+// evenly.  The last block also publishes the totals of the round.
+__global__ __launch_bounds__(BLOCK) void k_generate(DCamera cam, DState st, DRenderCtl* ctl, const uint32_t* surv, uint32_t* live,
+                                                    uint32_t n_sub, uint32_t cap, uint32_t parity, uint64_t seed, uint32_t spp_begin) {
+    __shared__ unsigned long long red_new[BLOCK / 64], red_surv[BLOCK / 64];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const unsigned long long next = ctl->next_path[parity];
     const unsigned long long left = ctl->total_paths - next;
-    const uint32_t room = capacity - n_surv;
-    const uint32_t n_new = left < room ? (uint32_t)left : room;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ctl->next_path[parity ^ 1u] = next + n_new;
-        ctl->count_live = n_surv + n_new;
-        ctl->rays += n_surv + n_new;
-        ctl->next_ray = 0u;
-        ctl->count_surv[parity ^ 1u] = 0u;
+    uint32_t share = cap;
+    if (left < (unsigned long long)n_sub * cap) share = (uint32_t)((left + n_sub - 1u) / n_sub);
+
+    const uint32_t first_sub = blockIdx.x * (BLOCK / 64);
+    unsigned long long sum_new = 0, sum_surv = 0;
+    for (uint32_t j = threadIdx.x; j < first_sub; j += BLOCK) {
+        const uint32_t sv = surv[j];
+        const uint32_t room = cap - sv;
+        sum_new += room < share ? room : share;
+        sum_surv += sv;
+    }
+    sum_new = wave_sum(sum_new);
+    sum_surv = wave_sum(sum_surv);
+    if (lane == 0) {
+        red_new[wave] = sum_new;
+        red_surv[wave] = sum_surv;
+    }
+    __syncthreads();
+    unsigned long long before = 0, surv_total = 0;   // over the sub-pools before this block's
+#pragma unroll
+    for (int q = 0; q < BLOCK / 64; ++q) {
+        before += red_new[q];
+        surv_total += red_surv[q];
+    }
+    // this block's own sub-pools, in order; never past the last path of the call
+    uint32_t my_surv = 0, my_new = 0;
+    unsigned long long my_first = next, block_new = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < BLOCK / 64; ++q) {
+        const uint32_t s2 = first_sub + q;
+        uint32_t sv = 0, want = 0;
+        if (s2 < n_sub) {
+            sv = surv[s2];
+            const uint32_t room = cap - sv;
+            want = room < share ? room : share;
+        }
+        const unsigned long long at = before + block_new;
+        const unsigned long long rest = left > at ? left - at : 0ull;
+        const uint32_t n_new = rest < want ? (uint32_t)rest : want;
+        if (q == wave) {
+            my_surv = sv;
+            my_new = n_new;
+            my_first = next + at;
+        }
+        block_new += n_new;
+        surv_total += sv;
+    }
+    const uint32_t w = first_sub + wave;
+    if (lane == 0 && w < n_sub) live[w] = my_surv + my_new;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        unsigned long long started = before + block_new;
+        if (started > left) started = left;
+        ctl->next_path[parity ^ 1u] = next + started;
+        ctl->live_total = (uint32_t)(surv_total + started);
+        ctl->rays += surv_total + started;
     }
     const unsigned long long npix = (unsigned long long)cam.image_width * cam.image_height;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_new; i += gridDim.x * BLOCK) {
+    const uint32_t slot0 = w * cap + my_surv;
+    for (uint32_t i = lane; i < my_new; i += 64u) {
         uint32_t pixel, sample_off;
-        split_path_index(next + i, npix, pixel, sample_off);
+        split_path_index(my_first + i, npix, pixel, sample_off);
         const uint32_t sample = spp_begin + sample_off;
         V3 o, d;
         uint32_t draw;
         start_path(cam, seed, pixel, sample, o, d, draw);
-        const uint32_t k = n_surv + i;
+        const uint32_t k = slot0 + i;
         st.ox[k] = o.x; st.oy[k] = o.y; st.oz[k] = o.z;
         st.dx[k] = d.x; st.dy[k] = d.y; st.dz[k] = d.z;
         st.bx[k] = 1.0; st.by[k] = 1.0; st.bz[k] = 1.0;
@@ -129,10 +207,10 @@ __global__ __launch_bounds__(BLOCK) void k_primary_rays(DCamera cam, uint64_t se
 // Second and third tier of the box test, out of line: the f64 filter on the
 // exact box and, if that is undecided too or the ray is outside the filter's
 // preconditions, the reference's division form.
-__device__ __noinline__ bool tier2_box(double2 q0, double2 q1, double2 q2, V3 o, V3 d, double tmin, double tmax, bool use_filter) {
+__device__ __noinline__ bool tier2_box(double2 q0, double2 q1, double2 q2, V3 o, V3 d, double tmin, double tmax, bool scene_filter) {
     const double bmin[3] = {q0.x, q0.y, q1.x};
     const double bmax[3] = {q1.y, q2.x, q2.y};
-    if (use_filter) {
+    if (scene_filter && filter_ray_ok(o, d, tmin, tmax)) {
         const V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
         FilterBounds fb;
         filter_set_tmin(fb, tmin);
@@ -162,12 +240,13 @@ __device__ __noinline__ bool tier2_box(double2 q0, double2 q1, double2 q2, V3 o,
 // their surface together.  A ray's own sequence of box and surface tests is
 // unchanged by this; only when the wave executes them is.
 template <bool COUNT, bool EXACT>
-__global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene sc, DState rays, DHits hits, const uint32_t* count_ptr,
+__global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene sc, DState rays, DHits hits, DPool pool,
                                                                         double tmin, double tmax0, DRenderCtl* ctl) {
-    const uint32_t count = *count_ptr;
+    const WaveSlot ws = wave_slot(pool);
+    const uint32_t count = ws.count;
     const uint32_t lane = lane_id();
-    const uint32_t tile_stride = gridDim.x * BLOCK;
-    uint32_t tile_base = (blockIdx.x * BLOCK + threadIdx.x) & ~63u;   // first ray of this wave's current tile
+    const uint32_t tile_stride = 64u;
+    uint32_t tile_base = 0u;   // first ray (offset in the wave's sub-pool) of the current tile
     const uint32_t end = sc.n_nodes;
     const bool scene_filter = !EXACT && sc.filter_ok != 0u;
 
@@ -182,14 +261,13 @@ __global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene s
     uint32_t c_nodes = 0, c_sph = 0, c_pln = 0;
 
     for (;;) {
-        // ---- refill: when every lane has retired, the wave takes its next tile of 64 rays.
-        // Tiles are dealt round-robin over the waves of the grid; a shared work
-        // counter would serialise on one L2 word (one atomic per 64 rays).
+        // ---- refill: when every lane has retired, the wave takes the next 64 rays of its sub-pool
         if (__ballot(idx != NONE) == 0ull) {
             if (tile_base >= count) break;
-            const uint32_t mine = tile_base + lane;
+            const uint32_t off = tile_base + lane;
             tile_base += tile_stride;
-            if (mine < count) {
+            if (off < count) {
+                const uint32_t mine = ws.base + off;
                 idx = mine;
                 o = v3(rays.ox[mine], rays.oy[mine], rays.oz[mine]);
                 d = v3(rays.dx[mine], rays.dy[mine], rays.dz[mine]);
@@ -297,40 +375,33 @@ __global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene s
 // few thousand nodes), so a visit costs two LDS reads and no trip through the
 // vector cache.
 template <bool COUNT, bool LDS_NODES>
-__global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, DHits hits, const uint32_t* count_ptr,
+__global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, DHits hits, DPool pool,
                                                         double tmin, double tmax0, DRenderCtl* ctl) {
     extern __shared__ uint4 lds_nodes[];   // LDS_NODES: 2 x uint4 per node
-    const uint32_t end = sc.n_nodes;
+    const uint32_t end = sc.n_nodes * 32u;   // nodes are addressed by the byte offset of their 32-byte record
     if (LDS_NODES) {
         const uint4* src = reinterpret_cast<const uint4*>(sc.nodes32);
-        for (uint32_t i = threadIdx.x; i < 2u * end; i += BLOCK) lds_nodes[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < 2u * sc.n_nodes; i += BLOCK) lds_nodes[i] = src[i];
         __syncthreads();
     }
-    const uint32_t count = *count_ptr;
+    const WaveSlot ws = wave_slot(pool);
+    const uint32_t count = ws.count;
     const uint32_t lane = lane_id();
-    // Tiles of 64 consecutive rays are dealt round-robin over the waves of the
-    // grid (neighbouring waves stream neighbouring memory).  A wave's own
-    // tiles form its private work list: position p of the list is ray
-    // (p & 63) of its (p >> 6)-th tile.  Idle lanes take the next positions
-    // of that list, so there is no shared work counter.
+    // The rays of the wave's sub-pool are its private work list; idle lanes
+    // take the next positions of it.
     constexpr uint32_t REFILL_AT = RTX_REFILL_AT;   // refill once this many lanes are idle
     constexpr uint32_t PEND_AT = RTX_PEND_AT;       // test surfaces once this many lanes stand on a leaf
-    const uint32_t n_waves = gridDim.x * (BLOCK / 64);
-    const uint32_t wave_global = (blockIdx.x * BLOCK + threadIdx.x) >> 6;
-    const uint32_t n_tiles = (count + 63u) >> 6;
-    const uint32_t my_tiles = wave_global < n_tiles ? (n_tiles - wave_global + n_waves - 1u) / n_waves : 0u;
-    const uint32_t p_end = my_tiles * 64u;
+    const uint32_t p_end = count;
     uint32_t next_p = 0;
     const bool scene_filter = sc.filter_ok != 0u;
 
     uint32_t idx = NONE;   // ray of this lane, NONE = idle
     V3 o = v3(0, 0, 0), d = v3(1, 1, 1);
     double tmax = tmax0, best_t = tmax0;
-    uint32_t best_leaf = NONE, node = 0;
-    bool use_f32 = false, use_filter = false;
+    uint32_t best_leaf = NONE, node = 0;   // node: byte offset of the f32 record (index * 32)
     RayF32 rf;
     rayf32_init(rf, o, d, tmin, tmax0);
-    uint32_t c_nodes = 0, c_sph = 0, c_pln = 0;
+    uint32_t c_nodes = 0, c_sph = 0, c_pln = 0, c_fallback = 0;
     bool pending = false;    // standing on a leaf whose box was hit, surface not tested yet
     uint32_t leaf = NONE;
 
@@ -342,8 +413,8 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, 
         if (next_p < p_end && (n_idle >= REFILL_AT || n_idle == 64u)) {
             const uint32_t p = next_p + rank_below(idle, lane);
             next_p += n_idle;
-            const uint32_t mine = ((wave_global + (p >> 6) * n_waves) << 6) | (p & 63u);
-            if (idx == NONE && p < p_end && mine < count) {
+            if (idx == NONE && p < p_end) {
+                const uint32_t mine = ws.base + p;
                 idx = mine;
                 o = v3(rays.ox[mine], rays.oy[mine], rays.oz[mine]);
                 d = v3(rays.dx[mine], rays.dy[mine], rays.dz[mine]);
@@ -351,9 +422,7 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, 
                 best_t = tmax0;
                 best_leaf = NONE;
                 node = 0;
-                use_filter = scene_filter && filter_ray_ok(o, d, tmin, tmax0);
-                const V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-                use_f32 = rayf32_init(rf, o, inv, tmin, tmax0) && use_filter;
+                rayf32_init(rf, o, d, tmin, tmax0);
             }
         }
 
@@ -365,10 +434,11 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, 
         while (searching) {       // lanes leave the loop one by one; the wave stays until all have left
             uint4 n0, n1;
             if (LDS_NODES) {
-                n0 = lds_nodes[2u * node];
-                n1 = lds_nodes[2u * node + 1u];
+                const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lds_nodes) + node);
+                n0 = np[0];
+                n1 = np[1];
             } else {
-                const uint4* np = reinterpret_cast<const uint4*>(sc.nodes32 + node);
+                const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + node);
                 n0 = np[0];
                 n1 = np[1];
             }
@@ -376,16 +446,16 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, 
             const float planes[6] = {__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z),
                                      __uint_as_float(n0.w), __uint_as_float(n1.x), __uint_as_float(n1.y)};
             int r = box_hit_f32(planes, rf);
-            if (!use_f32) r = -1;
             if (r < 0) {   // undecided in f32: the exact box, f64 filter, then the division form
-                const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + node);
+                const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> 5));
                 const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
-                r = tier2_box(q0, q1, q2, o, d, tmin, tmax, use_filter) ? 1 : 0;
+                if (COUNT) ++c_fallback;
+                r = tier2_box(q0, q1, q2, o, d, tmin, tmax, scene_filter) ? 1 : 0;
             }
             const bool hit = r > 0;
             const bool is_leaf = n1.w != NONE;
             const bool found = hit && is_leaf;
-            node = (hit && !is_leaf) ? node + 1u : n1.z;   // a leaf's successor is its miss link as well
+            node = (hit && !is_leaf) ? node + 32u : n1.z;   // links are byte offsets; a leaf's successor is its miss link as well
             leaf = found ? n1.w : leaf;
             pending = found;
             n_pending += (uint32_t)__popcll(__ballot(found));
@@ -436,6 +506,7 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, 
         atomicAdd(&ctl->node_visits, (unsigned long long)c_nodes);
         atomicAdd(&ctl->sphere_tests, (unsigned long long)c_sph);
         atomicAdd(&ctl->planar_tests, (unsigned long long)c_pln);
+        atomicAdd(&ctl->box_fallbacks, (unsigned long long)c_fallback);
     }
 }
 
@@ -457,45 +528,57 @@ __device__ __forceinline__ double reflectance(double cos_theta, double refractio
 // The reference nests `emitted + ray_color(..) * attenuation`; with emission
 // only on surfaces that do not scatter this is the same product of
 // attenuations, associated from the other end.
-__global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCamera cam, DState cur, DHits hits, const uint32_t* count_in,
-                                                 DState nxt, uint32_t* count_out, uint64_t seed, double* accum) {
-    __shared__ uint32_t wave_total[BLOCK / 64];
-    __shared__ uint32_t block_base;
-    const uint32_t count = *count_in;
+__global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCamera cam, DState cur, DHits hits, DPool pool,
+                                                                  DState nxt, uint32_t* counts_out, uint64_t seed, double* accum) {
+    // Every wave is on its own: it walks its sub-pool 64 rays at a time and
+    // appends the survivors, in order, to the same sub-pool of the other buffer.
+    const WaveSlot ws = wave_slot(pool);
+    const uint32_t count = ws.count;
     const uint32_t lane = lane_id();
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t stride = gridDim.x * BLOCK;
-    // the loop bound is block-uniform so every thread reaches the barriers
-    const uint32_t rounds = (count + stride - 1) / stride;
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t i = r * stride + blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t n_out = 0;   // survivors written so far (wave-uniform)
+    for (uint32_t t0 = 0; t0 < count; t0 += 64u) {
+        const uint32_t off = t0 + lane;
+        const uint32_t i = ws.base + off;
         bool alive = false;
         V3 p = v3(0, 0, 0), nd = v3(0, 0, 0), beta = v3(0, 0, 0);
         uint32_t pixel = 0, sample = 0, draw = 0, depth = 0;
-        if (i < count) {
-            const uint32_t prim = hits.prim[i];
+        if (off < count) {
+            // every load that does not depend on another is issued here, up
+            // front; the surface record is the only dependent round trip
+            const uint32_t handle = hits.prim[i];
+            const double t = hits.t[i];
+            const V3 o = v3(cur.ox[i], cur.oy[i], cur.oz[i]);
+            const V3 d = v3(cur.dx[i], cur.dy[i], cur.dz[i]);
             beta = v3(cur.bx[i], cur.by[i], cur.bz[i]);
             pixel = cur.pixel[i];
+            sample = cur.sample[i];
+            const uint32_t draw0 = cur.draw[i];
+            const uint32_t depth0 = cur.depth[i];
             V3 radiance = v3(0.0, 0.0, 0.0);
             bool add = false;
-            if (prim == NONE) {
+            if (handle == NONE) {
                 radiance = beta * ld3(cam.background);   // camera.rs:207
                 add = true;
             } else {
-                const V3 o = v3(cur.ox[i], cur.oy[i], cur.oz[i]);
-                const V3 d = v3(cur.dx[i], cur.dy[i], cur.dz[i]);
-                const double t = hits.t[i];
-                sample = cur.sample[i];
-                const DPrimInfo pi = sc.prims[prim];
-                const DMaterial m = sc.materials[pi.material];
+#ifdef RTX_X_NOREC
+                const uint32_t prim = 0;
+#else
+                const uint32_t prim = handle & HANDLE_PRIM_MASK;
+#endif
+                const uint32_t mkind = (handle >> 28) & 7u;
+                const bool planar = (handle >> 31) != 0u;
+                const double2* rp = reinterpret_cast<const double2*>(sc.shade_recs + prim);
+                const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+                const V3 rec_a = v3(r0.x, r0.y, r1.x);
+                const V3 rgb = v3(r2.x, r2.y, r3.x);
+                const double param = r3.y;
                 // complete the Hit for the winning surface (geometry.rs:232-249, 280-288)
                 p = o + d * t;
                 V3 outward;
                 double alpha = 0.0, beta_uv = 0.0;
-                if (pi.kind == 0u) {
-                    const DSphere s = sc.spheres[pi.slot];
-                    outward = (p - v3(s.c[0], s.c[1], s.c[2])) / s.r;
-                    if (m.kind == 4u) {   // u,v only feed UVGradient (geometry.rs:236-240)
+                if (!planar) {
+                    outward = (p - rec_a) * r1.y;   // (p - center) / radius
+                    if (mkind == 4u) {   // u,v only feed UVGradient (geometry.rs:236-240)
                         const double PI = 3.14159265358979323846264338327950288;
                         double theta = acos(-p.y);
                         double phi = atan2(-p.z, p.x) + PI;
@@ -503,9 +586,9 @@ __global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCa
                         beta_uv = theta / PI;
                     }
                 } else {
-                    const DPlanar& g = sc.planars[pi.slot];
-                    outward = ld3(g.norm);
-                    if (m.kind == 4u) {
+                    outward = rec_a;
+                    if (mkind == 4u) {
+                        const DPlanar& g = sc.planars[sc.prims[prim].slot];
                         V3 qp = p - ld3(g.q);
                         V3 w = ld3(g.w);
                         alpha = dot(w, cross(qp, ld3(g.v)));
@@ -516,41 +599,41 @@ __global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCa
                 const V3 n = front_face ? outward : -outward;
 
                 // Material::emitted, material.rs:35-54
-                if (m.kind == 3u) {
-                    radiance = beta * ld3(m.rgb);
+                if (mkind == 3u) {
+                    radiance = beta * rgb;
                     add = true;
-                } else if (m.kind == 4u) {
+                } else if (mkind == 4u) {
                     double a0 = 0.0 - alpha, a1 = 1.0 - alpha, b0 = 0.0 - beta_uv, b1 = 1.0 - beta_uv;
-                    V3 e = v3(1.0 - sqrt(a0 * a0 + b0 * b0), 1.0 - sqrt(a1 * a1 + b0 * b0), 1.0 - sqrt(a0 * a0 + b1 * b1)) * m.param;
+                    V3 e = v3(1.0 - sqrt(a0 * a0 + b0 * b0), 1.0 - sqrt(a1 * a1 + b0 * b0), 1.0 - sqrt(a0 * a0 + b1 * b1)) * param;
                     radiance = beta * e;
                     add = true;
                 }
 
                 // Material::scatter, material.rs:20-33
-                PathRng rng(seed, pixel, sample, cur.draw[i]);
+                PathRng rng(seed, pixel, sample, draw0);
                 rng.begin_event();
                 bool scattered = false;
                 V3 att = v3(1.0, 1.0, 1.0);
-                if (m.kind <= 1u) {
+                if (mkind <= 1u) {
                     // Lambertian and Metal both start with Vector3::random_unit()
                     // (material.rs:62, :86); one shared rejection loop for the wave
                     const V3 ru = random_unit(rng);
-                    att = ld3(m.rgb);
-                    if (m.kind == 0u) {        // lambertian, material.rs:61-73
+                    att = rgb;
+                    if (mkind == 0u) {        // lambertian, material.rs:61-73
                         V3 direction = n + ru;
                         if (is_near_zero(direction)) direction = n;
                         nd = direction;
                         scattered = true;
                     } else {                   // metal, material.rs:84-96
                         V3 reflected = reflect(d, n);
-                        V3 fuzz = ru * m.param;
+                        V3 fuzz = ru * param;
                         V3 fuzzed = to_unit(reflected) + fuzz;
                         nd = fuzzed;
                         scattered = dot(fuzzed, n) > 0.0;
                     }
-                } else if (m.kind == 2u) {     // dielectric, material.rs:108-130
+                } else if (mkind == 2u) {     // dielectric, material.rs:108-130
                     V3 r_in = to_unit(d);
-                    double eta = front_face ? 1.0 / m.param : m.param;
+                    double eta = front_face ? 1.0 / param : param;
                     double cos_theta = clampd(dot(-r_in, n), -1.0, 1.0);
                     double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
                     bool refl = eta * sin_theta > 1.0;
@@ -558,7 +641,7 @@ __global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCa
                     nd = refl ? reflect(r_in, n) : refract(r_in, n, eta);
                     scattered = true;
                 }
-                depth = cur.depth[i] + 1u;
+                depth = depth0 + 1u;
                 if (scattered && depth < cam.max_depth) {
                     beta = beta * att;
                     draw = rng.draw;
@@ -576,40 +659,25 @@ __global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCa
                 if (radiance.z != 0.0) unsafeAtomicAdd(px + 2, radiance.z);
             }
         }
-        // compaction: surviving paths go densely into the other state buffer.
-        // 64-wide ballot + prefix popcount inside a wave, wave totals summed
-        // through LDS, and ONE atomic per block and round: a returning atomic
-        // on a single L2 word sustains under 100 operations per microsecond,
-        // which one atomic per wave would exceed.
+        // compaction: 64-wide ballot + prefix popcount; the wave is the only writer of its sub-pool
         const unsigned long long amask = __ballot(alive);
-        if (lane == 0) wave_total[wave] = (uint32_t)__popcll(amask);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t total = 0;
-#pragma unroll
-            for (int w = 0; w < BLOCK / 64; ++w) {
-                const uint32_t c = wave_total[w];
-                wave_total[w] = total;   // exclusive prefix
-                total += c;
-            }
-            block_base = total ? atomicAdd(count_out, total) : 0u;
+#ifdef RTX_X_NOSTORE
+        if (alive && draw == 0xdeadbeefu) {
+#else
+        if (alive) {
+#endif
+            const uint32_t k = ws.base + n_out + rank_below(amask, lane);
+            nxt.ox[k] = p.x; nxt.oy[k] = p.y; nxt.oz[k] = p.z;
+            nxt.dx[k] = nd.x; nxt.dy[k] = nd.y; nxt.dz[k] = nd.z;
+            nxt.bx[k] = beta.x; nxt.by[k] = beta.y; nxt.bz[k] = beta.z;
+            nxt.pixel[k] = pixel;
+            nxt.sample[k] = sample;
+            nxt.draw[k] = draw;
+            nxt.depth[k] = depth;
         }
-        __syncthreads();
-        {
-            const uint32_t base = block_base + wave_total[wave];
-            if (alive) {
-                const uint32_t k = base + rank_below(amask, lane);
-                nxt.ox[k] = p.x; nxt.oy[k] = p.y; nxt.oz[k] = p.z;
-                nxt.dx[k] = nd.x; nxt.dy[k] = nd.y; nxt.dz[k] = nd.z;
-                nxt.bx[k] = beta.x; nxt.by[k] = beta.y; nxt.bz[k] = beta.z;
-                nxt.pixel[k] = pixel;
-                nxt.sample[k] = sample;
-                nxt.draw[k] = draw;
-                nxt.depth[k] = depth;
-            }
-        }
-        __syncthreads();   // wave_total / block_base are reused by the next round
+        n_out += (uint32_t)__popcll(amask);
     }
+    if (lane == 0 && ws.sub < pool.n_sub) counts_out[ws.sub] = n_out;
 }
 
 // ---------------------------------------------------------------- output stage
@@ -636,7 +704,7 @@ __global__ __launch_bounds__(BLOCK) void k_rays_to_state(const double* org, cons
 __global__ __launch_bounds__(BLOCK) void k_user_ids(const DPrimInfo* prims, uint32_t* ids, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
         uint32_t p = ids[i];
-        if (p != NONE) ids[i] = prims[p].user_id;
+        if (p != NONE) ids[i] = prims[p & HANDLE_PRIM_MASK].user_id;
     }
 }
 
@@ -645,6 +713,7 @@ __global__ void k_selftest_math(int op, const double* a, const double* b, uint64
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         if (op == 0) out[i] = a[i] / b[i];
         else if (op == 1) out[i] = sqrt(a[i]);
+        else if (op == 3) out[i] = (double)((float)a[i] / (float)b[i]);   // the f32 division the first box tier relies on
         else out[i] = a[i] * (1.0 / b[i]);
     }
 }
@@ -663,44 +732,44 @@ static inline uint32_t grid_for(uint64_t n, uint32_t max_blocks) {
     return (uint32_t)b;
 }
 
-void launch_generate(const DCamera& cam, const DState& st, uint32_t capacity, DRenderCtl* ctl, uint32_t parity, uint64_t seed,
-                     uint32_t spp_begin, uint32_t max_blocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(capacity, max_blocks)), dim3(BLOCK), 0, s, cam, st, capacity, ctl, parity, seed, spp_begin);
+// One wave per sub-pool.
+static inline uint32_t grid_for_pool(const uint32_t n_sub) { return (n_sub + BLOCK / 64 - 1) / (BLOCK / 64); }
+
+void launch_generate(const DCamera& cam, const DState& st, DRenderCtl* ctl, const uint32_t* surv, uint32_t* live, uint32_t n_sub,
+                     uint32_t sub_capacity, uint32_t parity, uint64_t seed, uint32_t spp_begin, hipStream_t s) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for_pool(n_sub)), dim3(BLOCK), 0, s, cam, st, ctl, surv, live, n_sub, sub_capacity, parity,
+                       seed, spp_begin);
 }
 void launch_primary_rays(const DCamera& cam, uint64_t seed, uint32_t sample, uint32_t npix, double* org, double* dir,
                          uint32_t max_blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_primary_rays, dim3(grid_for(npix, max_blocks)), dim3(BLOCK), 0, s, cam, seed, sample, npix, org, dir);
 }
-void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, const uint32_t* count_ptr,
-                     uint64_t max_count, double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool exact,
-                     uint32_t max_blocks, hipStream_t s) {
-    dim3 g(grid_for(max_count, max_blocks)), b(BLOCK);
+void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, const DPool& pool, double tmin, double tmax,
+                     DRenderCtl* ctl, bool count_work, bool exact, hipStream_t s) {
+    dim3 g(grid_for_pool(pool.n_sub)), b(BLOCK);
     if (count_work) {
-        if (exact) hipLaunchKernelGGL((k_traverse<true, true>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
-        else hipLaunchKernelGGL((k_traverse<true, false>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
+        if (exact) hipLaunchKernelGGL((k_traverse<true, true>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl);
+        else hipLaunchKernelGGL((k_traverse<true, false>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl);
     } else {
-        if (exact) hipLaunchKernelGGL((k_traverse<false, true>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
-        else hipLaunchKernelGGL((k_traverse<false, false>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
+        if (exact) hipLaunchKernelGGL((k_traverse<false, true>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl);
+        else hipLaunchKernelGGL((k_traverse<false, false>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl);
     }
 }
-void launch_traverse_f32(const DScene& sc, const DState& rays, const DHits& hits, const uint32_t* count_ptr, uint64_t max_count,
-                         double tmin, double tmax, DRenderCtl* ctl, bool count_work, bool lds_nodes, uint32_t max_blocks,
-                         hipStream_t s) {
-    dim3 g(grid_for(max_count, max_blocks)), b(BLOCK);
+void launch_traverse_f32(const DScene& sc, const DState& rays, const DHits& hits, const DPool& pool, double tmin, double tmax,
+                         DRenderCtl* ctl, bool count_work, bool lds_nodes, hipStream_t s) {
+    dim3 g(grid_for_pool(pool.n_sub)), b(BLOCK);
     const size_t lds = lds_nodes ? (size_t)sc.n_nodes * sizeof(DNode32) : 0;
     if (lds_nodes) {
-        if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, true>), g, b, lds, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
-        else hipLaunchKernelGGL((k_traverse_f32<false, true>), g, b, lds, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
+        if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, true>), g, b, lds, s, sc, rays, hits, pool, tmin, tmax, ctl);
+        else hipLaunchKernelGGL((k_traverse_f32<false, true>), g, b, lds, s, sc, rays, hits, pool, tmin, tmax, ctl);
     } else {
-        if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, false>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
-        else hipLaunchKernelGGL((k_traverse_f32<false, false>), g, b, 0, s, sc, rays, hits, count_ptr, tmin, tmax, ctl);
+        if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, false>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl);
+        else hipLaunchKernelGGL((k_traverse_f32<false, false>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl);
     }
 }
-void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const uint32_t* count_in,
-                  const DState& nxt, uint32_t* count_out, uint64_t max_count, uint64_t seed, double* accum, uint32_t max_blocks,
-                  hipStream_t s) {
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(max_count, max_blocks)), dim3(BLOCK), 0, s, sc, cam, cur, hits, count_in, nxt, count_out,
-                       seed, accum);
+void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const DPool& pool, const DState& nxt,
+                  uint32_t* counts_out, uint64_t seed, double* accum, hipStream_t s) {
+    hipLaunchKernelGGL(k_shade, dim3(grid_for_pool(pool.n_sub)), dim3(BLOCK), 0, s, sc, cam, cur, hits, pool, nxt, counts_out, seed, accum);
 }
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_scale, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, in, n, scale, out);

@@ -59,6 +59,22 @@ def test_device_division_and_sqrt_are_correctly_rounded(rt):
     assert np.array_equal(bits(got_sqrt)[~nan], bits(want_sqrt)[~nan])
 
 
+def test_device_f32_division_is_correctly_rounded(rt):
+    # the single-precision tier of the box test takes inv32 = 1.0f / RN32(d) to be within 2^-24 of the quotient
+    rng = np.random.default_rng(5)
+    n = 1 << 20
+    a = np.ones(n)
+    a[n // 2:] = rng.normal(size=n - n // 2) * 10.0 ** rng.integers(-15, 15, n - n // 2)
+    b = rng.normal(size=n) * 10.0 ** rng.integers(-30, 30, n)
+    b[:6] = [3.0, -7.0, 1e-30, 1e30, 0.1, 1.0]
+    with np.errstate(all="ignore"):
+        want = (a.astype(np.float32) / b.astype(np.float32)).astype(np.float64)
+    got = rt.selftest_math(3, a, b)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(bits(got)[~nan], bits(want)[~nan])
+
+
 def test_filtered_quotient_error_bound(rt):
     # the filtered box test relies on |a * RN(1/b) - RN(a/b)| <= 3 * 2^-53 |a/b|
     rng = np.random.default_rng(1)
