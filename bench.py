@@ -212,6 +212,7 @@ def main():
                 "launches": int(launches),
                 "nodes_per_ray": round(nv, 3),
                 "sphere_tests_per_ray": round(ns, 3),
+                "box_tests_left_to_f64_tiers": cnt.box_fallbacks / max(cnt.node_visits, 1),
                 "note": "the whole tree (31 KB of f32 node records) sits in LDS and the sphere table in L1/L2, so algorithmic bytes are "
                         "mostly served on-chip: the kernel is bound by VALU issue and divergence, not HBM; see valu_f64",
                 "valu_f64": {"achieved_tflops": round(achieved_tf, 3), "peak_tflops": FP64_VECTOR_PEAK_TF,

@@ -106,7 +106,7 @@ struct PathPool {
         return RTX_OK;
     }
     int ensure_capacity(size_t n) {
-        HIP_TRY(ctl.resize(1));
+        HIP_TRY(ctl.resize(4));   // the records behind the first are scratch for instrumented debug builds
         if (n <= capacity) return RTX_OK;
         HIP_TRY(buf_f64.resize(19 * n));
         HIP_TRY(buf_u32.resize(9 * n));
@@ -138,7 +138,7 @@ struct rtx_scene {
     DevBuf<DMaterial> materials;
     DevBuf<DNode32> nodes32;
     DevBuf<DBox64> boxes64;
-    DevBuf<uint32_t> sphere_prim, planar_prim;
+    DevBuf<uint32_t> rec_user_id;
     DevBuf<DShadeRec> shade_recs;
     bool f32_ok = false;   // every box plane is small enough for the single-precision tier
     // Lanes of the render loop, created on first use and kept.  Lane 0 also serves rtx_trace_closest.
@@ -222,15 +222,17 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     std::vector<DNode> nodes(n);
     std::vector<DNode32> nodes32(n);
     std::vector<DBox64> boxes64(n);
-    if (m > HANDLE_PRIM_MASK) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: more than 2^28 - 1 surfaces");
-    std::vector<uint32_t> sphere_prim, planar_prim, handle(m);
+    if (spheres.size() > CODE_SLOT_MASK || planars.size() > CODE_SLOT_MASK)
+        return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: more than 2^27 - 1 surfaces of one kind");
+    const uint32_t n_spheres = (uint32_t)spheres.size();
+    std::vector<uint32_t> code(m), rec_user_id(m);
     std::vector<DShadeRec> shade_recs(m);
     for (uint32_t i = 0; i < m; ++i) {
         const DMaterial& mt = mats[prims[i].material];
         const bool planar = prims[i].kind != RTX_SPHERE;
-        handle[i] = make_handle(i, mt.kind, planar);
-        (planar ? planar_prim : sphere_prim).push_back(handle[i]);
-        DShadeRec& r = shade_recs[i];
+        code[i] = make_code(prims[i].kind, mt.kind, prims[i].slot);
+        const uint32_t ri = planar ? n_spheres + prims[i].slot : prims[i].slot;
+        DShadeRec& r = shade_recs[ri];
         if (planar) {
             for (int a = 0; a < 3; ++a) r.a[a] = planars[prims[i].slot].norm[a];
             r.s = 0.0;
@@ -240,6 +242,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
         }
         for (int a = 0; a < 3; ++a) r.rgb[a] = mt.rgb[a];
         r.param = mt.param;
+        rec_user_id[ri] = prims[i].user_id;
     }
     bool f32_ok = true;
     std::vector<uint32_t> miss(n, NONE);
@@ -266,11 +269,10 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
             if (prim >= m) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: node_prim out of range");
             if (right != RTX_NONE) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: leaf with a right child");
             if (miss[i] != i + 1) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: leaf subtree is not a single node");
-            nd.prim = handle[prim];
+            nd.prim = code[prim];
             nd.kind = prims[prim].kind;
             nd.slot = prims[prim].slot;
-            if (nd.slot >= (1u << 30)) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: more than 2^30 surfaces of one kind");
-            nodes32[i].leaf = (nd.kind << 30) | nd.slot;
+            nodes32[i].leaf = code[prim];
         } else {                  // Node::Internal(Some(right_idx), box)
             if (right == RTX_NONE || right <= i + 1 || right >= miss[i])
                 return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: right child index out of order at node " + std::to_string(i));
@@ -307,8 +309,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     UP(materials, mats);
     UP(nodes32, nodes32);
     UP(boxes64, boxes64);
-    UP(sphere_prim, sphere_prim);
-    UP(planar_prim, planar_prim);
+    UP(rec_user_id, rec_user_id);
     UP(shade_recs, shade_recs);
 #undef UP
     sc->d.nodes = sc->nodes.p;
@@ -321,8 +322,9 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     sc->d.filter_ok = filter_ok ? 1u : 0u;
     sc->d.nodes32 = sc->nodes32.p;
     sc->d.boxes64 = sc->boxes64.p;
-    sc->d.sphere_prim = sc->sphere_prim.p;
-    sc->d.planar_prim = sc->planar_prim.p;
+    sc->d.n_spheres = n_spheres;
+    sc->d.n_planars = (uint32_t)planars.size();
+    sc->d.rec_user_id = sc->rec_user_id.p;
     sc->d.shade_recs = sc->shade_recs.p;
     sc->f32_ok = f32_ok && filter_ok;
     if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
@@ -356,14 +358,18 @@ static void pool_geometry(uint64_t need, uint32_t max_waves, uint32_t* n_sub, ui
 static void run_traverse(rtx_scene* sc, PathPool* pp, const DState& rays, const DPool& pool, double tmin, double tmax, uint32_t flags,
                          hipStream_t s) {
     const bool count_work = (flags & RTX_FLAG_COUNT_WORK) != 0;
-    const uint32_t lds_limit = env_u32("RTX_LDS_NODE_BYTES", 40u * 1024u);
+    const uint32_t lds_limit = env_u32("RTX_LDS_SCENE_BYTES", 32u * 1024u);   // five blocks of the kernel per CU
     if (flags & RTX_FLAG_EXACT_DIVIDE) {
         launch_traverse(sc->d, rays, pp->hits, pool, tmin, tmax, pp->ctl.p, count_work, true, s);
     } else if ((flags & RTX_FLAG_F64_FILTER) || !sc->f32_ok) {
         launch_traverse(sc->d, rays, pp->hits, pool, tmin, tmax, pp->ctl.p, count_work, false, s);
     } else {
-        const bool lds = !(flags & RTX_FLAG_NO_LDS) && (size_t)sc->d.n_nodes * sizeof(DNode32) <= lds_limit;
-        launch_traverse_f32(sc->d, rays, pp->hits, pool, tmin, tmax, pp->ctl.p, count_work, lds, s);
+        // the tree goes into LDS when its f32 records fit the budget, and the surface tables too when they also fit
+        const size_t tree = (size_t)sc->d.n_nodes * sizeof(DNode32);
+        const size_t surf = (size_t)sc->d.n_spheres * sizeof(DSphere) + (size_t)sc->d.n_planars * sizeof(DPlanar);
+        uint32_t mode = 0;
+        if (!(flags & RTX_FLAG_NO_LDS) && tree <= lds_limit) mode = tree + surf <= lds_limit ? 2u : 1u;
+        launch_traverse_f32(sc->d, rays, pp->hits, pool, tmin, tmax, pp->ctl.p, count_work, mode, s);
     }
 }
 
@@ -386,7 +392,7 @@ int rtx_trace_closest(rtx_scene* sc, const double* org, const double* dir, uint6
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (n == 0) return RTX_OK;
     HIP_TRY(hipSetDevice(sc->device));
-    const uint32_t max_waves = sc->n_cus * env_u32("RTX_BLOCKS_PER_CU", 8) * 4u;
+    const uint32_t max_waves = sc->n_cus * env_u32("RTX_WAVES_PER_CU", 20);
     uint32_t n_sub;
     uint64_t sub_capacity;
     pool_geometry(n, max_waves, &n_sub, &sub_capacity);
@@ -409,7 +415,7 @@ int rtx_trace_closest(rtx_scene* sc, const double* org, const double* dir, uint6
     HIP_TRY(hipEventRecord(sc->ev0, s));
     run_traverse(sc, pp, pp->state[0], pool, tmin, tmax, flags, s);
     HIP_TRY(hipEventRecord(sc->ev1, s));
-    launch_user_ids(sc->d.prims, pp->hits.prim, n, s);
+    launch_user_ids(sc->d.rec_user_id, sc->d.n_spheres, pp->hits.prim, n, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_id, pp->hits.prim, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(out_t, pp->hits.t, n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -502,7 +508,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     // The paths of the call are cut into contiguous ranges, one per lane; every lane has its own
     // pool of up to `want` slots (one slot per path for small calls), one sub-pool per wave of its launches.
     const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 22);
-    const uint32_t max_waves = sc->n_cus * env_u32("RTX_BLOCKS_PER_CU", 8) * 4u;
+    const uint32_t max_waves = sc->n_cus * env_u32("RTX_WAVES_PER_CU", 20);
     const uint32_t check_every = env_u32("RTX_CHECK_EVERY", 4);
     uint32_t n_lanes = env_u32("RTX_LANES", 2);
     if (n_lanes > 8) n_lanes = 8;
@@ -535,6 +541,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         h.next_path[0] = first;
         h.total_paths = last;
         HIP_TRY(hipMemcpyAsync(L.pp->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, ls));
+        HIP_TRY(hipMemsetAsync(L.pp->ctl.p + 1, 0, 3 * sizeof(DRenderCtl), ls));
         HIP_TRY(hipMemsetAsync(L.pp->counters.p, 0, 3 * (size_t)L.n_sub * sizeof(uint32_t), ls));
         L.pp->h_poll[0] = L.pp->h_poll[1] = 1u;
     }
@@ -656,6 +663,14 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
                 stats->ms_shade += b;
             }
             if (status == RTX_OK) status = read_counters(L.pp, L.pp->stream, stats);
+#ifdef RTX_PROFILE_PHASES
+            unsigned long long pr[14];
+            (void)hipMemcpy(pr, L.pp->ctl.p + 1, sizeof(pr), hipMemcpyDeviceToHost);
+            if (pr[7])
+                std::fprintf(stderr, "PHASES per wave: refill %.0f p1 %.0f p2 %.0f retire %.0f total %.0f cycles; p1 iterations %.1f, outer %.1f (waves %llu), wave life %.1f us; max over all waves and launches: life %.1f us, p1 iterations %llu, p1 cycles %llu; iterations with a fallback %.1f per wave costing %.0f cycles per wave\n",
+                             (double)pr[0] / pr[7], (double)pr[1] / pr[7], (double)pr[2] / pr[7], (double)pr[3] / pr[7], (double)pr[6] / pr[7],
+                             (double)pr[4] / pr[7], (double)pr[5] / pr[7], pr[7], (double)pr[8] / pr[7] / 100.0, (double)pr[9] / 100.0, pr[10], pr[11], (double)pr[12] / pr[7], (double)pr[13] / pr[7]);
+#endif
         }
     }
     return status;

@@ -37,7 +37,7 @@ static_assert(sizeof(DNode) == 64, "node record must be one 64-byte line");
 struct __attribute__((aligned(32))) DNode32 {
     float plane[6];   // lo.x, hi.x, lo.y, hi.y, lo.z, hi.z
     uint32_t miss;    // DNode::miss as the byte offset of that node's record (index * 32)
-    uint32_t leaf;    // NONE for an internal node, else (geometry kind << 30) | slot
+    uint32_t leaf;    // NONE for an internal node, else the surface code (make_code)
 };
 static_assert(sizeof(DNode32) == 32, "f32 node record must be 32 bytes");
 // The exact box of a node, for the rare visits the f32 tier cannot decide.
@@ -68,20 +68,26 @@ struct DMaterial {                              // enum Material, src/material.r
 //   sphere: a = center, s = 1.0 / radius  (`(p - c) / r` is `(p - c) * (1.0 / r)`, src/vector.rs:179-190)
 //   planar: a = norm,   s unused
 // plus the material's colour and parameter.  Geometry and material KIND do not
-// need a load at all: they travel in the hit handle.
+// need a load at all: they travel in the surface code.
 struct DShadeRec {
     double a[3];
     double s;
     double rgb[3];
     double param;
 };
-// Hit handle written by the closest-hit kernels: prim index in the low 28
-// bits, material kind in bits 28-30, bit 31 set for planar geometry.  NONE
-// (all ones) cannot collide: material kinds stop at 4.
-constexpr uint32_t HANDLE_PRIM_MASK = 0x0FFFFFFFu;
-__host__ __device__ inline uint32_t make_handle(uint32_t prim, uint32_t mat_kind, bool planar) {
-    return prim | (mat_kind << 28) | (planar ? 0x80000000u : 0u);
+// Surface code: how leaves name their surface and what the closest-hit
+// kernels write as the hit.  Geometry kind in bits 31-30, material kind in
+// bits 29-27, slot in the table of its geometry kind (spheres / planars) in
+// the low 27 bits.  NONE (all ones) cannot collide: geometry kinds stop at 2.
+// The shade kernel therefore knows both kinds without a load, and finds the
+// surface's shade record at index slot (spheres) or n_spheres + slot (planars).
+constexpr uint32_t CODE_SLOT_MASK = 0x07FFFFFFu;
+__host__ __device__ inline uint32_t make_code(uint32_t geom_kind, uint32_t mat_kind, uint32_t slot) {
+    return (geom_kind << 30) | (mat_kind << 27) | slot;
 }
+__host__ __device__ inline uint32_t code_geom(uint32_t c) { return c >> 30; }
+__host__ __device__ inline uint32_t code_mat(uint32_t c) { return (c >> 27) & 7u; }
+__host__ __device__ inline uint32_t code_slot(uint32_t c) { return c & CODE_SLOT_MASK; }
 
 struct DScene {
     const DNode* nodes;
@@ -94,9 +100,9 @@ struct DScene {
     uint32_t filter_ok;   // every box coordinate is finite and small enough for the filtered box test
     const DNode32* nodes32;
     const DBox64* boxes64;
-    const uint32_t* sphere_prim;   // slot in the sphere table -> hit handle of that prim
-    const uint32_t* planar_prim;   // slot in the planar table -> hit handle of that prim
-    const DShadeRec* shade_recs;   // per prim
+    uint32_t n_spheres, n_planars;
+    const DShadeRec* shade_recs;   // spheres by slot, then planars by slot
+    const uint32_t* rec_user_id;   // same order: index of the surface in the caller's array
 };
 
 // State of the paths in flight, struct-of-arrays.  Entry i of every array
@@ -111,7 +117,7 @@ struct DState {
 };
 // Closest-hit record of ray i of the current round.
 struct DHits {
-    uint32_t* prim;   // hit handle (make_handle) or NONE
+    uint32_t* prim;   // surface code (make_code) of the hit, or NONE
     double* t;
 };
 
@@ -415,8 +421,8 @@ __device__ __forceinline__ void rayf32_init(RayF32& r, V3 o, V3 d, double tmin, 
     r.K = ok ? oi_max * (8.1f * 0x1.0p-24f) + 2e-30f : __builtin_inff();
     rayf32_set_tmax(r, tmax);
 }
-// 1 = hit for certain, 0 = miss for certain, -1 = undecided
-__device__ __forceinline__ int box_hit_f32(const float p[6], const RayF32& r) {
+// Returns whether the answer is certain; `hit` is the answer when it is.
+__device__ __forceinline__ bool box_hit_f32(const float p[6], const RayF32& r, bool& hit) {
     const float t0x = fmaf(p[0], r.inv[0], -r.oi[0]), t1x = fmaf(p[1], r.inv[0], -r.oi[0]);
     const float t0y = fmaf(p[2], r.inv[1], -r.oi[1]), t1y = fmaf(p[3], r.inv[1], -r.oi[1]);
     const float t0z = fmaf(p[4], r.inv[2], -r.oi[2]), t1z = fmaf(p[5], r.inv[2], -r.oi[2]);
@@ -427,7 +433,8 @@ __device__ __forceinline__ int box_hit_f32(const float p[6], const RayF32& r) {
     const float M = fmaxf(fmaxf(-mn, mx), r.tg);
     const float T = fmaf(M, 12.2f * 0x1.0p-24f, r.K);
     const float m = fminf(fminf(hi - r.tmin32, r.tmax32 - lo), hi - lo);
-    return m > T ? 1 : (m < -T ? 0 : -1);
+    hit = m > T;
+    return hit || m < -T;
 }
 
 // ---------------------------------------------------------------- primitive tests

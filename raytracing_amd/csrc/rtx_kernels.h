@@ -12,13 +12,13 @@ void launch_primary_rays(const DCamera& cam, uint64_t seed, uint32_t sample, uin
 void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, const DPool& pool, double tmin, double tmax,
                      DRenderCtl* ctl, bool count_work, bool exact, hipStream_t s);
 void launch_traverse_f32(const DScene& sc, const DState& rays, const DHits& hits, const DPool& pool, double tmin, double tmax,
-                         DRenderCtl* ctl, bool count_work, bool lds_nodes, hipStream_t s);
+                         DRenderCtl* ctl, bool count_work, uint32_t lds_mode, hipStream_t s);
 void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const DPool& pool, const DState& nxt,
                   uint32_t* counts_out, uint64_t seed, double* accum, hipStream_t s);
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s);
 void launch_quantize(const double* in, uint64_t n, uint8_t* out, hipStream_t s);
 void launch_rays_to_state(const double* org, const double* dir, uint64_t n, const DState& st, hipStream_t s);
-void launch_user_ids(const DPrimInfo* prims, uint32_t* ids, uint64_t n, hipStream_t s);
+void launch_user_ids(const uint32_t* rec_user_id, uint32_t n_spheres, uint32_t* ids, uint64_t n, hipStream_t s);
 void launch_selftest_math(int op, const double* a, const double* b, uint64_t n, double* out, hipStream_t s);
 void launch_selftest_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, double* out, hipStream_t s);
 

@@ -16,9 +16,18 @@
 #include "rtx_device.h"
 #include "rtx_kernels.h"
 
+#include <cstdio>
+
 namespace rtx {
 
 constexpr int BLOCK = 256;
+// Block size of the closest-hit kernel with the tree in LDS.  Small blocks interleave best with the other
+// lane's kernels; five of them (5 waves per SIMD at this kernel's register count) share a CU's LDS.
+#ifndef RTX_TRAVERSE_LDS_BLOCK
+#define RTX_TRAVERSE_LDS_BLOCK 256
+#endif
+constexpr int TRAVERSE_LDS_BLOCK = RTX_TRAVERSE_LDS_BLOCK;
+constexpr uint32_t MAX_BLOCK_WAVES = TRAVERSE_LDS_BLOCK / 64 > BLOCK / 64 ? TRAVERSE_LDS_BLOCK / 64 : BLOCK / 64;   // waves per block of the largest closest-hit launch
 
 #ifndef RTX_SPHERE_PREFETCH
 #define RTX_SPHERE_PREFETCH 0
@@ -37,6 +46,8 @@ constexpr int BLOCK = 256;
 #endif
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+// 64-wide ballot straight from the condition mask (the generic __ballot first turns the flag into an integer)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t rank_below(unsigned long long mask, uint32_t lane) {
     return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
@@ -47,7 +58,7 @@ struct WaveSlot {
 };
 __device__ __forceinline__ WaveSlot wave_slot(const DPool& pool) {
     WaveSlot w;
-    w.sub = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + threadIdx.x) >> 6);
+    w.sub = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     w.base = w.sub * pool.sub_capacity;
     if (w.sub >= pool.n_sub) {
         w.count = 0u;
@@ -58,6 +69,13 @@ __device__ __forceinline__ WaveSlot wave_slot(const DPool& pool) {
         w.count = rest < pool.sub_capacity ? rest : pool.sub_capacity;
     }
     return w;
+}
+__device__ __forceinline__ uint32_t pool_count(const DPool& pool, uint32_t sub) {
+    if (sub >= pool.n_sub) return 0u;
+    if (pool.counts) return pool.counts[sub];
+    const uint32_t base = sub * pool.sub_capacity;
+    const uint32_t rest = pool.flat_total > base ? pool.flat_total - base : 0u;
+    return rest < pool.sub_capacity ? rest : pool.sub_capacity;
 }
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
@@ -86,8 +104,18 @@ __device__ __forceinline__ void start_path(const DCamera& cam, uint64_t seed, ui
     draw = rng.draw;
 }
 
-// Path g of a render call is sample (spp_begin + g / npix) of pixel g % npix,
-// so consecutive lanes start neighbouring pixels of one sample index.
+// Path g of a render call is sample (spp_begin + g / npix) of the pixel that
+// position g % npix of a scrambled pixel order names.  The order keeps runs of
+// 64 consecutive pixels together (a wave starts 64 neighbouring primary rays,
+// which walk the tree together) but sends consecutive runs to far-apart parts
+// of the image: run r of the order is run (r * RUN_STEP) mod n_runs of the
+// image.  A sub-pool therefore holds rays from all over the image, and the
+// cost of a sub-pool varies little from one to the next; with runs in image
+// order, the waves whose sub-pools hold an expensive region of the image take
+// several times longer than the rest.  The pixels after the last whole run
+// keep their place.  Which pixel a path index names does not change the
+// image: every (pixel, sample) is still rendered exactly once.
+constexpr unsigned long long RUN_STEP = 1000003ull;   // prime; a bijection on runs unless n_runs is a multiple of it
 __device__ __forceinline__ void split_path_index(unsigned long long g, unsigned long long npix, uint32_t& pixel, uint32_t& sample_off) {
     unsigned long long q;
     if (g < (1ull << 52)) {
@@ -100,7 +128,18 @@ __device__ __forceinline__ void split_path_index(unsigned long long g, unsigned 
         q = g / npix;
     }
     sample_off = (uint32_t)q;
-    pixel = (uint32_t)(g - q * npix);
+    const uint32_t pos = (uint32_t)(g - q * npix);
+    const uint32_t n_runs = (uint32_t)(npix >> 6);
+    uint32_t run = pos >> 6;
+    if (run < n_runs && n_runs % RUN_STEP != 0ull) {
+        const unsigned long long prod = (unsigned long long)run * (RUN_STEP % n_runs);   // < 2^32 * 2^32
+        // prod mod n_runs by one f64 division (prod < 2^52 for every image of at most 2^32 pixels)
+        unsigned long long qq = (unsigned long long)((double)prod / (double)n_runs);
+        if (qq * n_runs > prod) --qq;
+        else if ((qq + 1) * n_runs <= prod) ++qq;
+        run = (uint32_t)(prod - qq * n_runs);
+    }
+    pixel = (run << 6) | (pos & 63u);
 }
 
 // Appends new paths behind the survivors of every sub-pool of state buffer
@@ -262,7 +301,7 @@ __global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene s
 
     for (;;) {
         // ---- refill: when every lane has retired, the wave takes the next 64 rays of its sub-pool
-        if (__ballot(idx != NONE) == 0ull) {
+        if (ballot64(idx != NONE) == 0ull) {
             if (tile_base >= count) break;
             const uint32_t off = tile_base + lane;
             tile_base += tile_stride;
@@ -286,7 +325,7 @@ __global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene s
         bool pending = false;
         uint32_t leaf_kind = 0, leaf_slot = 0, leaf_prim = NONE;
         double2 sph_a = make_double2(0.0, 0.0), sph_b = make_double2(0.0, 0.0);
-        while (__ballot(searching) != 0ull) {
+        while (ballot64(searching) != 0ull) {
             if (searching) {
                 // the whole 64-byte record in four 16-byte loads issued back to back
                 const double2* np = reinterpret_cast<const double2*>(sc.nodes + node);
@@ -375,29 +414,56 @@ __global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene s
 // few thousand nodes), so a visit costs two LDS reads and no trip through the
 // vector cache.
 template <bool COUNT, bool LDS_NODES>
-__global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, DHits hits, DPool pool,
-                                                        double tmin, double tmax0, DRenderCtl* ctl) {
-    extern __shared__ uint4 lds_nodes[];   // LDS_NODES: 2 x uint4 per node
+__global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_traverse_f32(DScene sc, DState rays, DHits hits, DPool pool,
+                                                                                       double tmin, double tmax0, DRenderCtl* ctl,
+                                                                                       uint32_t lds_surfaces) {
+    // LDS_NODES: the f32 node records of the whole tree, then (lds_surfaces) the sphere and planar tables
+    extern __shared__ uint4 lds_nodes[];
     const uint32_t end = sc.n_nodes * 32u;   // nodes are addressed by the byte offset of their 32-byte record
+    const uint4* lds_spheres = lds_nodes + 2u * sc.n_nodes;
+    const uint4* lds_planars = lds_spheres + 2u * sc.n_spheres;
     if (LDS_NODES) {
         const uint4* src = reinterpret_cast<const uint4*>(sc.nodes32);
-        for (uint32_t i = threadIdx.x; i < 2u * sc.n_nodes; i += BLOCK) lds_nodes[i] = src[i];
-        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < 2u * sc.n_nodes; i += blockDim.x) lds_nodes[i] = src[i];
+        if (lds_surfaces) {
+            uint4* dst_s = lds_nodes + 2u * sc.n_nodes;
+            const uint4* src_s = reinterpret_cast<const uint4*>(sc.spheres);
+            for (uint32_t i = threadIdx.x; i < 2u * sc.n_spheres; i += blockDim.x) dst_s[i] = src_s[i];
+            uint4* dst_p = dst_s + 2u * sc.n_spheres;
+            const uint4* src_p = reinterpret_cast<const uint4*>(sc.planars);
+            for (uint32_t i = threadIdx.x; i < 8u * sc.n_planars; i += blockDim.x) dst_p[i] = src_p[i];
+        }
     }
-    const WaveSlot ws = wave_slot(pool);
-    const uint32_t count = ws.count;
+    // The rays of the block's sub-pools (one per wave of the block), end to
+    // end, are the block's work list.  Its waves draw from the list through
+    // one LDS cursor, so a wave that meets expensive rays simply draws less
+    // often; hits go to the ray's own slot, so it does not matter which wave
+    // traced a ray.  (Each wave tracing only its own sub-pool leaves most of a
+    // block idle while its slowest wave finishes.)
+    __shared__ uint32_t s_first[MAX_BLOCK_WAVES + 1];   // position of the first ray of each of the block's sub-pools
+    __shared__ uint32_t s_cursor;
+    const uint32_t block_waves = blockDim.x >> 6;
+    const uint32_t first_pool = blockIdx.x * block_waves;
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t j = 0; j < block_waves; ++j) {
+            s_first[j] = acc;
+            acc += pool_count(pool, first_pool + j);
+        }
+        for (uint32_t j = block_waves; j <= MAX_BLOCK_WAVES; ++j) s_first[j] = acc;
+        s_cursor = 0u;
+    }
+    __syncthreads();
     const uint32_t lane = lane_id();
-    // The rays of the wave's sub-pool are its private work list; idle lanes
-    // take the next positions of it.
     constexpr uint32_t REFILL_AT = RTX_REFILL_AT;   // refill once this many lanes are idle
     constexpr uint32_t PEND_AT = RTX_PEND_AT;       // test surfaces once this many lanes stand on a leaf
-    const uint32_t p_end = count;
-    uint32_t next_p = 0;
+    const uint32_t p_end = s_first[MAX_BLOCK_WAVES];
+    bool list_done = p_end == 0u;
     const bool scene_filter = sc.filter_ok != 0u;
 
     uint32_t idx = NONE;   // ray of this lane, NONE = idle
     V3 o = v3(0, 0, 0), d = v3(1, 1, 1);
-    double tmax = tmax0, best_t = tmax0;
+    double tmax = tmax0;   // == t of the best hit so far once there is one
     uint32_t best_leaf = NONE, node = 0;   // node: byte offset of the f32 record (index * 32)
     RayF32 rf;
     rayf32_init(rf, o, d, tmin, tmax0);
@@ -405,27 +471,43 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, 
     bool pending = false;    // standing on a leaf whose box was hit, surface not tested yet
     uint32_t leaf = NONE;
 
+#ifdef RTX_PROFILE_PHASES
+    long long pt_fb_iters = 0, pt_fb_cycles = 0, pt_refill = 0, pt_p1 = 0, pt_p2 = 0, pt_retire = 0, pt_iters = 0, pt_outer = 0, pt_mark = clock64();
+    const long long pt_begin = pt_mark, pt_wall_begin = wall_clock64();
+#define PT(acc) do { const long long now_ = clock64(); acc += now_ - pt_mark; pt_mark = now_; } while (0)
+#else
+#define PT(acc) do {} while (0)
+#endif
     for (;;) {
         // ---- refill idle lanes from the wave's work list once enough of them are idle
-        const unsigned long long idle = __ballot(idx == NONE);
+        const unsigned long long idle = ballot64(idx == NONE);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (n_idle == 64u && next_p >= p_end) break;
-        if (next_p < p_end && (n_idle >= REFILL_AT || n_idle == 64u)) {
-            const uint32_t p = next_p + rank_below(idle, lane);
-            next_p += n_idle;
+        if (n_idle == 64u && list_done) break;
+        if (!list_done && (n_idle >= REFILL_AT || n_idle == 64u)) {
+            uint32_t start = 0;
+            if (lane == 0) start = atomicAdd(&s_cursor, n_idle);
+            start = __builtin_amdgcn_readfirstlane(start);
+            list_done = start + n_idle >= p_end;
+            const uint32_t p = start + rank_below(idle, lane);
             if (idx == NONE && p < p_end) {
-                const uint32_t mine = ws.base + p;
+                uint32_t j = 0;   // which of the block's sub-pools position p falls in
+#pragma unroll
+                for (uint32_t q = 1; q < MAX_BLOCK_WAVES; ++q) j += p >= s_first[q] ? 1u : 0u;
+                const uint32_t mine = (first_pool + j) * pool.sub_capacity + (p - s_first[j]);
                 idx = mine;
                 o = v3(rays.ox[mine], rays.oy[mine], rays.oz[mine]);
                 d = v3(rays.dx[mine], rays.dy[mine], rays.dz[mine]);
                 tmax = tmax0;
-                best_t = tmax0;
                 best_leaf = NONE;
                 node = 0;
                 rayf32_init(rf, o, d, tmin, tmax0);
             }
         }
 
+        PT(pt_refill);
+#ifdef RTX_PROFILE_PHASES
+        ++pt_outer;
+#endif
         // ---- phase 1: walk to the next leaf whose box is hit
         // (a lane that found its leaf waits; the loop also ends as soon as
         // PEND_AT lanes are waiting, so a few long searches do not stall them)
@@ -445,32 +527,46 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, 
             if (COUNT) ++c_nodes;
             const float planes[6] = {__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z),
                                      __uint_as_float(n0.w), __uint_as_float(n1.x), __uint_as_float(n1.y)};
-            int r = box_hit_f32(planes, rf);
-            if (r < 0) {   // undecided in f32: the exact box, f64 filter, then the division form
+            bool hit;
+#ifdef RTX_PROFILE_PHASES
+            const bool decided_ = box_hit_f32(planes, rf, hit);
+            const long long fb0_ = clock64();
+            if (ballot64(!decided_) != 0ull) ++pt_fb_iters;
+            if (!decided_) {
+#else
+            if (!box_hit_f32(planes, rf, hit)) {   // undecided in f32: the exact box, f64 filter, then the division form
+#endif
                 const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> 5));
                 const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
                 if (COUNT) ++c_fallback;
-                r = tier2_box(q0, q1, q2, o, d, tmin, tmax, scene_filter) ? 1 : 0;
+                hit = tier2_box(q0, q1, q2, o, d, tmin, tmax, scene_filter);
             }
-            const bool hit = r > 0;
+#ifdef RTX_PROFILE_PHASES
+            pt_fb_cycles += clock64() - fb0_;
+#endif
             const bool is_leaf = n1.w != NONE;
             const bool found = hit && is_leaf;
             node = (hit && !is_leaf) ? node + 32u : n1.z;   // links are byte offsets; a leaf's successor is its miss link as well
             leaf = found ? n1.w : leaf;
             pending = found;
-            n_pending += (uint32_t)__popcll(__ballot(found));
+            n_pending += (uint32_t)__popcll(ballot64(found));
             searching = !found && node < end;
+#ifdef RTX_PROFILE_PHASES
+            ++pt_iters;
+#endif
             if (n_pending >= PEND_AT) break;   // wave-uniform
         }
+        PT(pt_p1);
 
         // ---- phase 2: surface tests of the lanes standing on a leaf
         if (pending) {
-            const uint32_t kind = leaf >> 30, slot = leaf & 0x3FFFFFFFu;
+            const uint32_t kind = code_geom(leaf), slot = code_slot(leaf);
             double t;
             bool ph;
             if (kind == 0u) {
                 if (COUNT) ++c_sph;
-                const double2* spp = reinterpret_cast<const double2*>(sc.spheres + slot);
+                const double2* spp = (LDS_NODES && lds_surfaces) ? reinterpret_cast<const double2*>(lds_spheres + 2u * slot)
+                                                                 : reinterpret_cast<const double2*>(sc.spheres + slot);
                 const double2 sa = spp[0], sb = spp[1];
                 DSphere sp;
                 sp.c[0] = sa.x; sp.c[1] = sa.y; sp.c[2] = sb.x; sp.r = sb.y;
@@ -478,30 +574,46 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_f32(DScene sc, DState rays, 
             } else {
                 if (COUNT) ++c_pln;
                 double al, be;
-                ph = planar_t(sc.planars[slot], kind, o, d, tmin, tmax, t, al, be);
+                const DPlanar* gp = (LDS_NODES && lds_surfaces) ? reinterpret_cast<const DPlanar*>(lds_planars + 8u * slot) : sc.planars + slot;
+                ph = planar_t(*gp, kind, o, d, tmin, tmax, t, al, be);
             }
             // `if let Some(nearest) = acc && hit.t > nearest.t { keep } else { replace }`
-            if (ph && !(best_leaf != NONE && t > best_t)) {
+            if (ph && !(best_leaf != NONE && t > tmax)) {
                 best_leaf = leaf;
-                best_t = t;
                 tmax = t;   // shrunken_ray_t.max = hit.t
                 rayf32_set_tmax(rf, t);
             }
             pending = false;
         }
 
+        PT(pt_p2);
         // ---- retire rays that have run out of tree
         if (idx != NONE && node >= end) {
-            uint32_t prim = NONE;
-            if (best_leaf != NONE) {
-                const uint32_t slot = best_leaf & 0x3FFFFFFFu;
-                prim = (best_leaf >> 30) == 0u ? sc.sphere_prim[slot] : sc.planar_prim[slot];
-            }
-            hits.prim[idx] = prim;
-            hits.t[idx] = best_t;
+            hits.prim[idx] = best_leaf;
+            hits.t[idx] = tmax;
             idx = NONE;
         }
+        PT(pt_retire);
     }
+#ifdef RTX_PROFILE_PHASES
+    if (lane == 0 && ctl && p_end > 0) {
+        unsigned long long* pr = reinterpret_cast<unsigned long long*>(ctl + 1);   // debug area behind the control block
+        atomicAdd(pr + 0, (unsigned long long)pt_refill);
+        atomicAdd(pr + 1, (unsigned long long)pt_p1);
+        atomicAdd(pr + 2, (unsigned long long)pt_p2);
+        atomicAdd(pr + 3, (unsigned long long)pt_retire);
+        atomicAdd(pr + 4, (unsigned long long)pt_iters);
+        atomicAdd(pr + 5, (unsigned long long)pt_outer);
+        atomicAdd(pr + 6, (unsigned long long)(clock64() - pt_begin));
+        atomicAdd(pr + 7, 1ull);
+        atomicAdd(pr + 8, (unsigned long long)(wall_clock64() - pt_wall_begin));
+        atomicMax(pr + 9, (unsigned long long)(wall_clock64() - pt_wall_begin));
+        atomicMax(pr + 10, (unsigned long long)pt_iters);
+        atomicMax(pr + 11, (unsigned long long)pt_p1);
+        atomicAdd(pr + 12, (unsigned long long)pt_fb_iters);
+        atomicAdd(pr + 13, (unsigned long long)pt_fb_cycles);
+    }
+#endif
     if (COUNT && ctl) {
         atomicAdd(&ctl->node_visits, (unsigned long long)c_nodes);
         atomicAdd(&ctl->sphere_tests, (unsigned long long)c_sph);
@@ -560,14 +672,9 @@ __global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCa
                 radiance = beta * ld3(cam.background);   // camera.rs:207
                 add = true;
             } else {
-#ifdef RTX_X_NOREC
-                const uint32_t prim = 0;
-#else
-                const uint32_t prim = handle & HANDLE_PRIM_MASK;
-#endif
-                const uint32_t mkind = (handle >> 28) & 7u;
-                const bool planar = (handle >> 31) != 0u;
-                const double2* rp = reinterpret_cast<const double2*>(sc.shade_recs + prim);
+                const uint32_t mkind = code_mat(handle), slot = code_slot(handle);
+                const bool planar = code_geom(handle) != 0u;
+                const double2* rp = reinterpret_cast<const double2*>(sc.shade_recs + (planar ? sc.n_spheres + slot : slot));
                 const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
                 const V3 rec_a = v3(r0.x, r0.y, r1.x);
                 const V3 rgb = v3(r2.x, r2.y, r3.x);
@@ -588,7 +695,7 @@ __global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCa
                 } else {
                     outward = rec_a;
                     if (mkind == 4u) {
-                        const DPlanar& g = sc.planars[sc.prims[prim].slot];
+                        const DPlanar& g = sc.planars[slot];
                         V3 qp = p - ld3(g.q);
                         V3 w = ld3(g.w);
                         alpha = dot(w, cross(qp, ld3(g.v)));
@@ -648,11 +755,7 @@ __global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCa
                     alive = true;
                 }
             }
-#ifdef RTX_EXPERIMENT_NO_ATOMICS   // timing experiment only
-            if (add && radiance.x == 123.456) {
-#else
             if (add) {
-#endif
                 double* px = accum + 3 * (size_t)pixel;
                 if (radiance.x != 0.0) unsafeAtomicAdd(px + 0, radiance.x);
                 if (radiance.y != 0.0) unsafeAtomicAdd(px + 1, radiance.y);
@@ -660,12 +763,8 @@ __global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCa
             }
         }
         // compaction: 64-wide ballot + prefix popcount; the wave is the only writer of its sub-pool
-        const unsigned long long amask = __ballot(alive);
-#ifdef RTX_X_NOSTORE
-        if (alive && draw == 0xdeadbeefu) {
-#else
+        const unsigned long long amask = ballot64(alive);
         if (alive) {
-#endif
             const uint32_t k = ws.base + n_out + rank_below(amask, lane);
             nxt.ox[k] = p.x; nxt.oy[k] = p.y; nxt.oz[k] = p.z;
             nxt.dx[k] = nd.x; nxt.dy[k] = nd.y; nxt.dz[k] = nd.z;
@@ -701,10 +800,10 @@ __global__ __launch_bounds__(BLOCK) void k_rays_to_state(const double* org, cons
         st.dx[i] = dir[3 * i + 0]; st.dy[i] = dir[3 * i + 1]; st.dz[i] = dir[3 * i + 2];
     }
 }
-__global__ __launch_bounds__(BLOCK) void k_user_ids(const DPrimInfo* prims, uint32_t* ids, uint64_t n) {
+__global__ __launch_bounds__(BLOCK) void k_user_ids(const uint32_t* rec_user_id, uint32_t n_spheres, uint32_t* ids, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
         uint32_t p = ids[i];
-        if (p != NONE) ids[i] = prims[p & HANDLE_PRIM_MASK].user_id;
+        if (p != NONE) ids[i] = rec_user_id[(code_geom(p) != 0u ? n_spheres : 0u) + code_slot(p)];
     }
 }
 
@@ -756,15 +855,29 @@ void launch_traverse(const DScene& sc, const DState& rays, const DHits& hits, co
     }
 }
 void launch_traverse_f32(const DScene& sc, const DState& rays, const DHits& hits, const DPool& pool, double tmin, double tmax,
-                         DRenderCtl* ctl, bool count_work, bool lds_nodes, hipStream_t s) {
-    dim3 g(grid_for_pool(pool.n_sub)), b(BLOCK);
-    const size_t lds = lds_nodes ? (size_t)sc.n_nodes * sizeof(DNode32) : 0;
-    if (lds_nodes) {
-        if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, true>), g, b, lds, s, sc, rays, hits, pool, tmin, tmax, ctl);
-        else hipLaunchKernelGGL((k_traverse_f32<false, true>), g, b, lds, s, sc, rays, hits, pool, tmin, tmax, ctl);
+                         DRenderCtl* ctl, bool count_work, uint32_t lds_mode, hipStream_t s) {
+    // lds_mode 0: tree in global memory; 1: tree in LDS; 2: tree and surface tables in LDS
+    if (lds_mode) {
+        const uint32_t waves_per_block = TRAVERSE_LDS_BLOCK / 64;
+        dim3 g((pool.n_sub + waves_per_block - 1) / waves_per_block), b(TRAVERSE_LDS_BLOCK);
+        size_t lds = (size_t)sc.n_nodes * sizeof(DNode32);
+        const uint32_t surf = lds_mode == 2u ? 1u : 0u;
+        if (surf) lds += (size_t)sc.n_spheres * sizeof(DSphere) + (size_t)sc.n_planars * sizeof(DPlanar);
+#ifdef RTX_PROFILE_PHASES
+        static bool once = false;
+        if (!once) {
+            once = true;
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_traverse_f32<false, true>, TRAVERSE_LDS_BLOCK, lds);
+            std::fprintf(stderr, "OCCUPANCY k_traverse_f32<false,true>: %d blocks of %d threads per CU with %zu B LDS; grid %u\n", nb, TRAVERSE_LDS_BLOCK, lds, g.x);
+        }
+#endif
+        if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, true>), g, b, lds, s, sc, rays, hits, pool, tmin, tmax, ctl, surf);
+        else hipLaunchKernelGGL((k_traverse_f32<false, true>), g, b, lds, s, sc, rays, hits, pool, tmin, tmax, ctl, surf);
     } else {
-        if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, false>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl);
-        else hipLaunchKernelGGL((k_traverse_f32<false, false>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl);
+        dim3 g(grid_for_pool(pool.n_sub)), b(BLOCK);
+        if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, false>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
+        else hipLaunchKernelGGL((k_traverse_f32<false, false>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
     }
 }
 void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const DPool& pool, const DState& nxt,
@@ -780,8 +893,8 @@ void launch_quantize(const double* in, uint64_t n, uint8_t* out, hipStream_t s) 
 void launch_rays_to_state(const double* org, const double* dir, uint64_t n, const DState& st, hipStream_t s) {
     hipLaunchKernelGGL(k_rays_to_state, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, org, dir, n, st);
 }
-void launch_user_ids(const DPrimInfo* prims, uint32_t* ids, uint64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_user_ids, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, prims, ids, n);
+void launch_user_ids(const uint32_t* rec_user_id, uint32_t n_spheres, uint32_t* ids, uint64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_user_ids, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, rec_user_id, n_spheres, ids, n);
 }
 void launch_selftest_math(int op, const double* a, const double* b, uint64_t n, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_selftest_math, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, op, a, b, n, out);
