@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel (the metric is quoted at 500)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-kernels", action="store_true", help="round-loop path with per-kernel HIP event timing (diagnostic)")
     args = ap.parse_args()
 
     import torch
@@ -137,7 +138,7 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    stats = [step(rt.FLAG_TIME_KERNELS) for _ in range(args.steps)]
+    stats = [step(rt.FLAG_TIME_KERNELS if args.time_kernels else 0) for _ in range(args.steps)]
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -157,20 +158,20 @@ def main():
         # algorithmic work per ray from an untimed counting pass over this rank's samples
         cnt = scene.render_accumulate(icam, SEED, begin, min(count, 4), acc.data_ptr(), stream, rt.FLAG_COUNT_WORK)
         nv, ns, npl = cnt.node_visits / cnt.rays, cnt.sphere_tests / cnt.rays, cnt.planar_tests / cnt.rays
-        # traverse kernel: node records + primitive records + ray read + hit record write
-        bytes_per_ray = 56.0 * nv + 32.0 * ns + 128.0 * npl + 48.0 + 12.0
-        flops_per_ray = 37.0 * nv + 30.0 * ns + 57.0 * npl
-        launches = sum(s.iterations for s in stats)
-        trav_ms = sum(s.ms_traverse for s in stats)
-        shade_ms = sum(s.ms_shade for s in stats)
-        gen_ms = sum(s.ms_generate for s in stats)
+        # The whole sample loop is ONE kernel launch per step (k_render_persistent), timed with HIP events on its
+        # stream inside rtx_render_accumulate (stats.ms_total).  Algorithmic work per ray, whole path:
+        #   bytes = 56 Nv + 32 Ns + 128 Np (nodes, spheres, planars) + 40 (material) + 160 (ray state read + write) + 12 (hit record),
+        #           plus 12 B per path for the accumulation;  flops = 37 Nv + 30 Ns + 57 Np + 60
         rank_rays = sum(s.rays for s in stats)
+        rank_paths = sum(s.paths for s in stats)
+        bytes_per_ray = 56.0 * nv + 32.0 * ns + 128.0 * npl + 212.0 + 12.0 * rank_paths / max(rank_rays, 1)
+        flops_per_ray = 37.0 * nv + 30.0 * ns + 57.0 * npl + 60.0
+        launches = len(stats)
         rays_per_launch = rank_rays / launches
-        avg_launch_ms = trav_ms / launches
+        avg_launch_ms = sum(s.ms_total for s in stats) / launches
         achieved_gbs = bytes_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e9
         achieved_tf = flops_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e12
-
-        kernel = "k_traverse_f32"
+        kernel = "k_render_persistent"
         traffic, traffic_src = measured_traffic(kernel)
 
         out = {
@@ -213,12 +214,15 @@ def main():
                 "nodes_per_ray": round(nv, 3),
                 "sphere_tests_per_ray": round(ns, 3),
                 "box_tests_left_to_f64_tiers": cnt.box_fallbacks / max(cnt.node_visits, 1),
-                "note": "the whole tree (31 KB of f32 node records) sits in LDS and the sphere table in L1/L2, so algorithmic bytes are "
-                        "mostly served on-chip: the kernel is bound by VALU issue and divergence, not HBM; see valu_f64",
+                "note": "one persistent launch renders the frame; the tree (31 KB of f32 node records) sits in LDS and the sphere table "
+                        "in L1/L2, so most algorithmic bytes are served on-chip and only the ray state, hit records and accumulation "
+                        "reach HBM (traffic): the kernel is bound by VALU issue and divergence; see valu_f64",
                 "valu_f64": {"achieved_tflops": round(achieved_tf, 3), "peak_tflops": FP64_VECTOR_PEAK_TF,
                              "frac": round(achieved_tf / FP64_VECTOR_PEAK_TF, 4), "flops_per_ray": round(flops_per_ray, 1)},
-                "kernel_time_share": {"traverse_ms": round(trav_ms / args.steps, 2), "shade_ms": round(shade_ms / args.steps, 2),
-                                      "generate_ms": round(gen_ms / args.steps, 2)},
+                "rounds_of_busiest_wave": int(max(s.iterations for s in stats)),
+                "kernel_time_share": {"traverse_ms": round(sum(s.ms_traverse for s in stats) / args.steps, 2),
+                                      "shade_ms": round(sum(s.ms_shade for s in stats) / args.steps, 2),
+                                      "generate_ms": round(sum(s.ms_generate for s in stats) / args.steps, 2)},
             },
         }
         if not args.no_cpu_baseline and world == 1:

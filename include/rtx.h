@@ -102,7 +102,7 @@ typedef struct rtx_stats {
     uint64_t sphere_tests;
     uint64_t planar_tests;
     uint64_t box_fallbacks;  /* box tests the single-precision tier left to the f64 tiers (counted with node_visits) */
-    uint64_t iterations;     /* generate+traverse+shade rounds launched, over all lanes */
+    uint64_t iterations;     /* single-launch render: rounds of the busiest wave; round loop: rounds launched, over all lanes */
     double   ms_total;       /* device time of the call, HIP events */
     double   ms_traverse;    /* summed duration of the traverse kernel launches (0 unless RTX_FLAG_TIME_KERNELS). */
     double   ms_shade;       /* A render call runs several independent lanes side by side on their own streams, */
@@ -113,7 +113,7 @@ typedef struct rtx_scene rtx_scene;
 
 /* flags for rtx_render_accumulate / rtx_trace_closest */
 #define RTX_FLAG_COUNT_WORK   1u  /* fill node_visits / *_tests (slower) */
-#define RTX_FLAG_TIME_KERNELS 2u  /* time every traverse / shade launch with HIP events */
+#define RTX_FLAG_TIME_KERNELS 2u  /* render with the round loop (generate / traverse / shade launches) and time every launch with HIP events */
 #define RTX_FLAG_EXACT_DIVIDE 4u  /* box test by six true divisions per node, exactly as src/aabb.rs:55-76 */
 #define RTX_FLAG_F64_FILTER   8u  /* skip the single-precision tier of the box test */
 #define RTX_FLAG_NO_LDS       16u /* keep the f32 node records in global memory even when they fit in LDS */

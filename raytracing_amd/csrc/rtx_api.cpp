@@ -78,6 +78,7 @@ struct PathPool {
     DevBuf<DRenderCtl> ctl;
     DevBuf<uint32_t> counters;  // per sub-pool: live, survivors[0], survivors[1]
     uint32_t counters_n = 0;
+    DevBuf<DRenderParams> params;   // launch record of the single-launch render
     DState state[2]{};
     DHits hits{};
     hipStream_t stream = nullptr;            // owned
@@ -351,6 +352,15 @@ static void pool_geometry(uint64_t need, uint32_t max_waves, uint32_t* n_sub, ui
     *sub_capacity = (((need + waves - 1) / waves) + 63) & ~63ull;
 }
 
+// 0: tree in global memory; 1: f32 node records in LDS; 2: node records and surface tables in LDS
+static uint32_t lds_mode_for(const rtx_scene* sc, uint32_t flags) {
+    const uint32_t lds_limit = env_u32("RTX_LDS_SCENE_BYTES", 32u * 1024u);   // five blocks of the kernel per CU
+    const size_t tree = (size_t)sc->d.n_nodes * sizeof(DNode32);
+    const size_t surf = (size_t)sc->d.n_spheres * sizeof(DSphere) + (size_t)sc->d.n_planars * sizeof(DPlanar);
+    if ((flags & RTX_FLAG_NO_LDS) || tree > lds_limit) return 0u;
+    return tree + surf <= lds_limit ? 2u : 1u;
+}
+
 // Which closest-hit kernel a call uses: the reference's division form when the
 // caller asks for it, else the tiered test with the f32 records in LDS (small
 // trees), from global memory (large trees), or the f64-only filter (scenes
@@ -358,17 +368,12 @@ static void pool_geometry(uint64_t need, uint32_t max_waves, uint32_t* n_sub, ui
 static void run_traverse(rtx_scene* sc, PathPool* pp, const DState& rays, const DPool& pool, double tmin, double tmax, uint32_t flags,
                          hipStream_t s) {
     const bool count_work = (flags & RTX_FLAG_COUNT_WORK) != 0;
-    const uint32_t lds_limit = env_u32("RTX_LDS_SCENE_BYTES", 32u * 1024u);   // five blocks of the kernel per CU
     if (flags & RTX_FLAG_EXACT_DIVIDE) {
         launch_traverse(sc->d, rays, pp->hits, pool, tmin, tmax, pp->ctl.p, count_work, true, s);
     } else if ((flags & RTX_FLAG_F64_FILTER) || !sc->f32_ok) {
         launch_traverse(sc->d, rays, pp->hits, pool, tmin, tmax, pp->ctl.p, count_work, false, s);
     } else {
-        // the tree goes into LDS when its f32 records fit the budget, and the surface tables too when they also fit
-        const size_t tree = (size_t)sc->d.n_nodes * sizeof(DNode32);
-        const size_t surf = (size_t)sc->d.n_spheres * sizeof(DSphere) + (size_t)sc->d.n_planars * sizeof(DPlanar);
-        uint32_t mode = 0;
-        if (!(flags & RTX_FLAG_NO_LDS) && tree <= lds_limit) mode = tree + surf <= lds_limit ? 2u : 1u;
+        const uint32_t mode = lds_mode_for(sc, flags);
         launch_traverse_f32(sc->d, rays, pp->hits, pool, tmin, tmax, pp->ctl.p, count_work, mode, s);
     }
 }
@@ -504,6 +509,62 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(RTX_ERR_BAD_ARG, "rtx_render_accumulate: sample index overflow");
     HIP_TRY(hipSetDevice(sc->device));
     hipStream_t s = (hipStream_t)stream;
+
+    // Default path: the whole sample loop as ONE launch of persistent waves on the caller's stream.  It needs the
+    // single-precision box tier; calls that ask for another tier, or scenes outside its range, take the round loop below.
+    if (sc->f32_ok && !(flags & (RTX_FLAG_EXACT_DIVIDE | RTX_FLAG_F64_FILTER | RTX_FLAG_TIME_KERNELS)) && env_u32("RTX_PERSISTENT", 1) == 1u) {
+        PathPool* pp = sc->lane(0);
+        const uint32_t mode = lds_mode_for(sc, flags);
+        const uint32_t waves = sc->n_cus * persistent_blocks_per_cu(sc->d, mode) * 4u;   // exactly what is resident at once
+        const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 23);   // 2048 slots per wave: a wave's round ends with a drain, so long rounds pay
+        const uint64_t need = total < want ? total : want;
+        uint32_t n_sub;
+        uint64_t per_sub;
+        pool_geometry(need, waves, &n_sub, &per_sub);
+        if (per_sub * n_sub > 0xFFFFFFFFull) return fail(RTX_ERR_BAD_ARG, "rtx_render_accumulate: pool larger than 2^32-1 slots");
+        rc = pp->ensure_capacity((size_t)per_sub * n_sub);
+        if (rc != RTX_OK) return rc;
+        HIP_TRY(pp->params.resize(1));
+        DRenderCtl h{};
+        h.total_paths = total;
+        DRenderParams P{};
+        P.sc = sc->d;
+        P.cam = to_dcamera(cam);
+        P.st[0] = pp->state[0];
+        P.st[1] = pp->state[1];
+        P.hits = pp->hits;
+        P.ctl = pp->ctl.p;
+        P.accum = d_accum;
+        P.seed = seed;
+        P.tmin = 0.001;   // Interval(0.001, inf), camera.rs:194
+        P.tmax0 = INFINITY;
+        P.n_sub = n_sub;
+        P.cap = (uint32_t)per_sub;
+        P.spp_begin = spp_begin;
+        P.lds_surfaces = mode == 2u ? 1u : 0u;
+        HIP_TRY(hipMemcpyAsync(pp->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(pp->params.p, &P, sizeof(P), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(sc->ev0, s));
+        launch_render_persistent(pp->params.p, P, (flags & RTX_FLAG_COUNT_WORK) != 0, mode, s);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(sc->ev1, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (stats) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, sc->ev0, sc->ev1);
+            stats->ms_total = ms;
+            stats->paths = total;
+            DRenderCtl back;
+            HIP_TRY(hipMemcpy(&back, pp->ctl.p, sizeof(back), hipMemcpyDeviceToHost));
+            stats->rays = back.rays;
+            stats->node_visits = back.node_visits;
+            stats->sphere_tests = back.sphere_tests;
+            stats->planar_tests = back.planar_tests;
+            stats->box_fallbacks = back.box_fallbacks;
+            stats->iterations = back.rounds_max;
+        }
+        return RTX_OK;
+    }
 
     // The paths of the call are cut into contiguous ranges, one per lane; every lane has its own
     // pool of up to `want` slots (one slot per path for small calls), one sub-pool per wave of its launches.

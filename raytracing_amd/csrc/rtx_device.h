@@ -155,7 +155,22 @@ struct DRenderCtl {
     unsigned long long node_visits, sphere_tests, planar_tests;
     unsigned long long box_fallbacks;  // box tests the f32 tier left undecided
     uint32_t live_total;               // rays of the current round over all sub-pools (the host polls this)
-    uint32_t _pad;
+    uint32_t rounds_max;               // single-launch render: most rounds any wave went through
+};
+
+// Everything the single-launch render kernel needs, in device memory: the
+// kernel and its phases take one pointer and load what they use, instead of
+// holding some 120 scalar registers of launch arguments for their whole life.
+struct DRenderParams {
+    DScene sc;
+    DCamera cam;
+    DState st[2];
+    DHits hits;
+    DRenderCtl* ctl;
+    double* accum;
+    unsigned long long seed;
+    double tmin, tmax0;
+    uint32_t n_sub, cap, spp_begin, lds_surfaces;
 };
 
 // ---------------------------------------------------------------- Vector3 (src/vector.rs)

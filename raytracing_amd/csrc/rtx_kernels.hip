@@ -36,7 +36,10 @@ constexpr uint32_t MAX_BLOCK_WAVES = TRAVERSE_LDS_BLOCK / 64 > BLOCK / 64 ? TRAV
 #define RTX_TRAVERSE_WAVES 1
 #endif
 #ifndef RTX_SHADE_WAVES
-#define RTX_SHADE_WAVES 1
+#define RTX_SHADE_WAVES 4
+#endif
+#ifndef RTX_PERSISTENT_WAVES
+#define RTX_PERSISTENT_WAVES 4
 #endif
 #ifndef RTX_REFILL_AT
 #define RTX_REFILL_AT 32
@@ -48,6 +51,11 @@ constexpr uint32_t MAX_BLOCK_WAVES = TRAVERSE_LDS_BLOCK / 64 > BLOCK / 64 ? TRAV
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 // 64-wide ballot straight from the condition mask (the generic __ballot first turns the flag into an integer)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// readfirstlane as unsigned (the builtin returns int, which would sign-extend when widened) and for 64-bit values
+__device__ __forceinline__ uint32_t uniform32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    return ((unsigned long long)uniform32((uint32_t)(v >> 32)) << 32) | (unsigned long long)uniform32((uint32_t)v);
+}
 __device__ __forceinline__ uint32_t rank_below(unsigned long long mask, uint32_t lane) {
     return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
@@ -58,7 +66,7 @@ struct WaveSlot {
 };
 __device__ __forceinline__ WaveSlot wave_slot(const DPool& pool) {
     WaveSlot w;
-    w.sub = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    w.sub = uniform32((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     w.base = w.sub * pool.sub_capacity;
     if (w.sub >= pool.n_sub) {
         w.count = 0u;
@@ -142,6 +150,28 @@ __device__ __forceinline__ void split_path_index(unsigned long long g, unsigned 
     pixel = (run << 6) | (pos & 63u);
 }
 
+// The wave starts paths first .. first + n_new - 1 in slots slot0 .. of `st`.
+__device__ __forceinline__ void generate_wave(const DCamera& cam, const DState& st, uint32_t slot0, unsigned long long first, uint32_t n_new,
+                                              uint64_t seed, uint32_t spp_begin) {
+    const unsigned long long npix = (unsigned long long)cam.image_width * cam.image_height;
+    for (uint32_t i = lane_id(); i < n_new; i += 64u) {
+        uint32_t pixel, sample_off;
+        split_path_index(first + i, npix, pixel, sample_off);
+        const uint32_t sample = spp_begin + sample_off;
+        V3 o, d;
+        uint32_t draw;
+        start_path(cam, seed, pixel, sample, o, d, draw);
+        const uint32_t k = slot0 + i;
+        st.ox[k] = o.x; st.oy[k] = o.y; st.oz[k] = o.z;
+        st.dx[k] = d.x; st.dy[k] = d.y; st.dz[k] = d.z;
+        st.bx[k] = 1.0; st.by[k] = 1.0; st.bz[k] = 1.0;
+        st.pixel[k] = pixel;
+        st.sample[k] = sample;
+        st.draw[k] = draw;
+        st.depth[k] = 0u;
+    }
+}
+
 // Appends new paths behind the survivors of every sub-pool of state buffer
 // `st` until the sub-pool is full or every path of the call has been started,
 // and publishes the round's ray counts.  Sub-pool s takes the path indices
@@ -211,24 +241,7 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DCamera cam, DState st, DRen
         ctl->live_total = (uint32_t)(surv_total + started);
         ctl->rays += surv_total + started;
     }
-    const unsigned long long npix = (unsigned long long)cam.image_width * cam.image_height;
-    const uint32_t slot0 = w * cap + my_surv;
-    for (uint32_t i = lane; i < my_new; i += 64u) {
-        uint32_t pixel, sample_off;
-        split_path_index(my_first + i, npix, pixel, sample_off);
-        const uint32_t sample = spp_begin + sample_off;
-        V3 o, d;
-        uint32_t draw;
-        start_path(cam, seed, pixel, sample, o, d, draw);
-        const uint32_t k = slot0 + i;
-        st.ox[k] = o.x; st.oy[k] = o.y; st.oz[k] = o.z;
-        st.dx[k] = d.x; st.dy[k] = d.y; st.dz[k] = d.z;
-        st.bx[k] = 1.0; st.by[k] = 1.0; st.bz[k] = 1.0;
-        st.pixel[k] = pixel;
-        st.sample[k] = sample;
-        st.draw[k] = draw;
-        st.depth[k] = 0u;
-    }
+    generate_wave(cam, st, w * cap + my_surv, my_first, my_new, seed, spp_begin);
 }
 
 // Primary rays only, for the parity API (rays laid out [n][3]).
@@ -413,53 +426,34 @@ __global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene s
 // the f32 records of the whole tree are first copied into LDS (scenes up to a
 // few thousand nodes), so a visit costs two LDS reads and no trip through the
 // vector cache.
-template <bool COUNT, bool LDS_NODES>
-__global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_traverse_f32(DScene sc, DState rays, DHits hits, DPool pool,
-                                                                                       double tmin, double tmax0, DRenderCtl* ctl,
-                                                                                       uint32_t lds_surfaces) {
-    // LDS_NODES: the f32 node records of the whole tree, then (lds_surfaces) the sphere and planar tables
-    extern __shared__ uint4 lds_nodes[];
-    const uint32_t end = sc.n_nodes * 32u;   // nodes are addressed by the byte offset of their 32-byte record
-    const uint4* lds_spheres = lds_nodes + 2u * sc.n_nodes;
-    const uint4* lds_planars = lds_spheres + 2u * sc.n_spheres;
-    if (LDS_NODES) {
-        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes32);
-        for (uint32_t i = threadIdx.x; i < 2u * sc.n_nodes; i += blockDim.x) lds_nodes[i] = src[i];
-        if (lds_surfaces) {
-            uint4* dst_s = lds_nodes + 2u * sc.n_nodes;
-            const uint4* src_s = reinterpret_cast<const uint4*>(sc.spheres);
-            for (uint32_t i = threadIdx.x; i < 2u * sc.n_spheres; i += blockDim.x) dst_s[i] = src_s[i];
-            uint4* dst_p = dst_s + 2u * sc.n_spheres;
-            const uint4* src_p = reinterpret_cast<const uint4*>(sc.planars);
-            for (uint32_t i = threadIdx.x; i < 8u * sc.n_planars; i += blockDim.x) dst_p[i] = src_p[i];
-        }
-    }
-    // The rays of the block's sub-pools (one per wave of the block), end to
-    // end, are the block's work list.  Its waves draw from the list through
-    // one LDS cursor, so a wave that meets expensive rays simply draws less
-    // often; hits go to the ray's own slot, so it does not matter which wave
-    // traced a ray.  (Each wave tracing only its own sub-pool leaves most of a
-    // block idle while its slowest wave finishes.)
-    __shared__ uint32_t s_first[MAX_BLOCK_WAVES + 1];   // position of the first ray of each of the block's sub-pools
-    __shared__ uint32_t s_cursor;
-    const uint32_t block_waves = blockDim.x >> 6;
-    const uint32_t first_pool = blockIdx.x * block_waves;
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (uint32_t j = 0; j < block_waves; ++j) {
-            s_first[j] = acc;
-            acc += pool_count(pool, first_pool + j);
-        }
-        for (uint32_t j = block_waves; j <= MAX_BLOCK_WAVES; ++j) s_first[j] = acc;
-        s_cursor = 0u;
-    }
-    __syncthreads();
+// Work list and scene staging of one wave of the closest-hit walk.
+struct TraverseWork {
+    const uint4* lds_nodes;     // LDS copy of the f32 node records (LDS_NODES)
+    const uint4* lds_spheres;   // LDS copies of the surface tables (lds_surfaces)
+    const uint4* lds_planars;
+    uint32_t lds_surfaces;
+    // SHARED: the block's sub-pools end to end, drawn through an LDS cursor
+    const uint32_t* s_first;
+    uint32_t* s_cursor;
+    uint32_t first_pool, sub_capacity;
+    // !SHARED: `count` rays from slot `base` on, the wave's own
+    uint32_t base, count;
+};
+struct WorkCounters {
+    unsigned long long nodes = 0, spheres = 0, planars = 0, fallbacks = 0;
+};
+
+template <bool COUNT, bool LDS_NODES, bool SHARED>
+__device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState& rays, const DHits& hits, const TraverseWork& w, double tmin,
+                                                  double tmax0, DRenderCtl* ctl, WorkCounters& wc) {
     const uint32_t lane = lane_id();
     constexpr uint32_t REFILL_AT = RTX_REFILL_AT;   // refill once this many lanes are idle
     constexpr uint32_t PEND_AT = RTX_PEND_AT;       // test surfaces once this many lanes stand on a leaf
-    const uint32_t p_end = s_first[MAX_BLOCK_WAVES];
+    const uint32_t p_end = SHARED ? w.s_first[MAX_BLOCK_WAVES] : w.count;
     bool list_done = p_end == 0u;
+    uint32_t next_p = 0;   // !SHARED: next position of the wave's own list
     const bool scene_filter = sc.filter_ok != 0u;
+    const uint32_t end = sc.n_nodes * 32u;   // nodes are addressed by the byte offset of their 32-byte record
 
     uint32_t idx = NONE;   // ray of this lane, NONE = idle
     V3 o = v3(0, 0, 0), d = v3(1, 1, 1);
@@ -484,16 +478,23 @@ __global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_trav
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (n_idle == 64u && list_done) break;
         if (!list_done && (n_idle >= REFILL_AT || n_idle == 64u)) {
-            uint32_t start = 0;
-            if (lane == 0) start = atomicAdd(&s_cursor, n_idle);
-            start = __builtin_amdgcn_readfirstlane(start);
+            uint32_t start = next_p;
+            if (SHARED) {
+                if (lane == 0) start = atomicAdd(w.s_cursor, n_idle);
+                start = uniform32(start);
+            } else {
+                next_p += n_idle;
+            }
             list_done = start + n_idle >= p_end;
             const uint32_t p = start + rank_below(idle, lane);
             if (idx == NONE && p < p_end) {
-                uint32_t j = 0;   // which of the block's sub-pools position p falls in
+                uint32_t mine = w.base + p;
+                if (SHARED) {
+                    uint32_t j = 0;   // which of the block's sub-pools position p falls in
 #pragma unroll
-                for (uint32_t q = 1; q < MAX_BLOCK_WAVES; ++q) j += p >= s_first[q] ? 1u : 0u;
-                const uint32_t mine = (first_pool + j) * pool.sub_capacity + (p - s_first[j]);
+                    for (uint32_t q = 1; q < MAX_BLOCK_WAVES; ++q) j += p >= w.s_first[q] ? 1u : 0u;
+                    mine = (w.first_pool + j) * w.sub_capacity + (p - w.s_first[j]);
+                }
                 idx = mine;
                 o = v3(rays.ox[mine], rays.oy[mine], rays.oz[mine]);
                 d = v3(rays.dx[mine], rays.dy[mine], rays.dz[mine]);
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_trav
         while (searching) {       // lanes leave the loop one by one; the wave stays until all have left
             uint4 n0, n1;
             if (LDS_NODES) {
-                const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lds_nodes) + node);
+                const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + node);
                 n0 = np[0];
                 n1 = np[1];
             } else {
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_trav
             bool ph;
             if (kind == 0u) {
                 if (COUNT) ++c_sph;
-                const double2* spp = (LDS_NODES && lds_surfaces) ? reinterpret_cast<const double2*>(lds_spheres + 2u * slot)
+                const double2* spp = (LDS_NODES && w.lds_surfaces) ? reinterpret_cast<const double2*>(w.lds_spheres + 2u * slot)
                                                                  : reinterpret_cast<const double2*>(sc.spheres + slot);
                 const double2 sa = spp[0], sb = spp[1];
                 DSphere sp;
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_trav
             } else {
                 if (COUNT) ++c_pln;
                 double al, be;
-                const DPlanar* gp = (LDS_NODES && lds_surfaces) ? reinterpret_cast<const DPlanar*>(lds_planars + 8u * slot) : sc.planars + slot;
+                const DPlanar* gp = (LDS_NODES && w.lds_surfaces) ? reinterpret_cast<const DPlanar*>(w.lds_planars + 8u * slot) : sc.planars + slot;
                 ph = planar_t(*gp, kind, o, d, tmin, tmax, t, al, be);
             }
             // `if let Some(nearest) = acc && hit.t > nearest.t { keep } else { replace }`
@@ -614,11 +615,70 @@ __global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_trav
         atomicAdd(pr + 13, (unsigned long long)pt_fb_cycles);
     }
 #endif
+    if (COUNT) {
+        wc.nodes += c_nodes;
+        wc.spheres += c_sph;
+        wc.planars += c_pln;
+        wc.fallbacks += c_fallback;
+    }
+}
+
+template <bool COUNT, bool LDS_NODES>
+__global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_traverse_f32(DScene sc, DState rays, DHits hits, DPool pool,
+                                                                                       double tmin, double tmax0, DRenderCtl* ctl,
+                                                                                       uint32_t lds_surfaces) {
+    // LDS_NODES: the f32 node records of the whole tree, then (lds_surfaces) the sphere and planar tables
+    extern __shared__ uint4 lds_nodes[];
+    const uint4* lds_spheres = lds_nodes + 2u * sc.n_nodes;
+    const uint4* lds_planars = lds_spheres + 2u * sc.n_spheres;
+    if (LDS_NODES) {
+        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes32);
+        for (uint32_t i = threadIdx.x; i < 2u * sc.n_nodes; i += blockDim.x) lds_nodes[i] = src[i];
+        if (lds_surfaces) {
+            uint4* dst_s = lds_nodes + 2u * sc.n_nodes;
+            const uint4* src_s = reinterpret_cast<const uint4*>(sc.spheres);
+            for (uint32_t i = threadIdx.x; i < 2u * sc.n_spheres; i += blockDim.x) dst_s[i] = src_s[i];
+            uint4* dst_p = dst_s + 2u * sc.n_spheres;
+            const uint4* src_p = reinterpret_cast<const uint4*>(sc.planars);
+            for (uint32_t i = threadIdx.x; i < 8u * sc.n_planars; i += blockDim.x) dst_p[i] = src_p[i];
+        }
+    }
+    // The rays of the block's sub-pools (one per wave of the block), end to
+    // end, are the block's work list.  Its waves draw from the list through
+    // one LDS cursor, so a wave that meets expensive rays simply draws less
+    // often; hits go to the ray's own slot, so it does not matter which wave
+    // traced a ray.  (Each wave tracing only its own sub-pool leaves most of a
+    // block idle while its slowest wave finishes.)
+    __shared__ uint32_t s_first[MAX_BLOCK_WAVES + 1];   // position of the first ray of each of the block's sub-pools
+    __shared__ uint32_t s_cursor;
+    const uint32_t block_waves = blockDim.x >> 6;
+    const uint32_t first_pool = blockIdx.x * block_waves;
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t j = 0; j < block_waves; ++j) {
+            s_first[j] = acc;
+            acc += pool_count(pool, first_pool + j);
+        }
+        for (uint32_t j = block_waves; j <= MAX_BLOCK_WAVES; ++j) s_first[j] = acc;
+        s_cursor = 0u;
+    }
+    __syncthreads();
+    TraverseWork w{};
+    w.lds_nodes = lds_nodes;
+    w.lds_spheres = lds_spheres;
+    w.lds_planars = lds_planars;
+    w.lds_surfaces = lds_surfaces;
+    w.s_first = s_first;
+    w.s_cursor = &s_cursor;
+    w.first_pool = first_pool;
+    w.sub_capacity = pool.sub_capacity;
+    WorkCounters wc;
+    traverse_f32_wave<COUNT, LDS_NODES, true>(sc, rays, hits, w, tmin, tmax0, ctl, wc);
     if (COUNT && ctl) {
-        atomicAdd(&ctl->node_visits, (unsigned long long)c_nodes);
-        atomicAdd(&ctl->sphere_tests, (unsigned long long)c_sph);
-        atomicAdd(&ctl->planar_tests, (unsigned long long)c_pln);
-        atomicAdd(&ctl->box_fallbacks, (unsigned long long)c_fallback);
+        atomicAdd(&ctl->node_visits, wc.nodes);
+        atomicAdd(&ctl->sphere_tests, wc.spheres);
+        atomicAdd(&ctl->planar_tests, wc.planars);
+        atomicAdd(&ctl->box_fallbacks, wc.fallbacks);
     }
 }
 
@@ -640,17 +700,16 @@ __device__ __forceinline__ double reflectance(double cos_theta, double refractio
 // The reference nests `emitted + ray_color(..) * attenuation`; with emission
 // only on surfaces that do not scatter this is the same product of
 // attenuations, associated from the other end.
-__global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCamera cam, DState cur, DHits hits, DPool pool,
-                                                                  DState nxt, uint32_t* counts_out, uint64_t seed, double* accum) {
-    // Every wave is on its own: it walks its sub-pool 64 rays at a time and
-    // appends the survivors, in order, to the same sub-pool of the other buffer.
-    const WaveSlot ws = wave_slot(pool);
-    const uint32_t count = ws.count;
+// The wave walks `count` rays from slot `base` on, 64 at a time, and appends
+// the survivors, in order, from slot `base` of the other buffer on.  Returns
+// the number of survivors.
+__device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, uint32_t base,
+                                               uint32_t count, const DState& nxt, uint64_t seed, double* accum) {
     const uint32_t lane = lane_id();
     uint32_t n_out = 0;   // survivors written so far (wave-uniform)
     for (uint32_t t0 = 0; t0 < count; t0 += 64u) {
         const uint32_t off = t0 + lane;
-        const uint32_t i = ws.base + off;
+        const uint32_t i = base + off;
         bool alive = false;
         V3 p = v3(0, 0, 0), nd = v3(0, 0, 0), beta = v3(0, 0, 0);
         uint32_t pixel = 0, sample = 0, draw = 0, depth = 0;
@@ -765,7 +824,7 @@ __global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCa
         // compaction: 64-wide ballot + prefix popcount; the wave is the only writer of its sub-pool
         const unsigned long long amask = ballot64(alive);
         if (alive) {
-            const uint32_t k = ws.base + n_out + rank_below(amask, lane);
+            const uint32_t k = base + n_out + rank_below(amask, lane);
             nxt.ox[k] = p.x; nxt.oy[k] = p.y; nxt.oz[k] = p.z;
             nxt.dx[k] = nd.x; nxt.dy[k] = nd.y; nxt.dz[k] = nd.z;
             nxt.bx[k] = beta.x; nxt.by[k] = beta.y; nxt.bz[k] = beta.z;
@@ -776,7 +835,142 @@ __global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCa
         }
         n_out += (uint32_t)__popcll(amask);
     }
-    if (lane == 0 && ws.sub < pool.n_sub) counts_out[ws.sub] = n_out;
+    return n_out;
+}
+
+// Every wave is on its own sub-pool.
+__global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCamera cam, DState cur, DHits hits, DPool pool,
+                                                                  DState nxt, uint32_t* counts_out, uint64_t seed, double* accum) {
+    const WaveSlot ws = wave_slot(pool);
+    const uint32_t n_out = shade_wave(sc, cam, cur, hits, ws.base, ws.count, nxt, seed, accum);
+    if (lane_id() == 0 && ws.sub < pool.n_sub) counts_out[ws.sub] = n_out;
+}
+
+// ---------------------------------------------------------------- whole render in one launch
+// Every wave owns a sub-pool and cycles through top-up -> closest hit -> shade
+// on it until the call's paths are used up and its sub-pool is empty.  Waves
+// never wait for each other (a slow wave just completes fewer rounds), the
+// host is not involved between rounds, and at any moment the waves of a SIMD
+// are in different phases, so the closest-hit walk (bound by VALU issue)
+// overlaps shading (bound by memory latency) without any scheduling effort.
+// The only shared words are the path counter (one returning atomic per wave
+// and round) and the accumulation buffer.  A sub-pool is written and read by
+// its own wave only; workgroup-scope fences order the phases.
+// The three phases are separate functions, not inlined: each gets its own
+// register allocation (the kernel's register count is the largest of them, not
+// their sum), and a call per phase per round costs nothing against the phase.
+__device__ __forceinline__ const DRenderParams* uniform_ptr(const DRenderParams* p) {
+    return (const DRenderParams*)uniform64((unsigned long long)p);
+}
+__device__ __noinline__ void phase_generate(const DRenderParams* pp, uint32_t parity, uint32_t slot0, unsigned long long first, uint32_t got) {
+    const DRenderParams* P = uniform_ptr(pp);
+    parity = uniform32(parity);
+    slot0 = uniform32(slot0);
+    got = uniform32(got);
+    first = uniform64(first);
+    generate_wave(P->cam, P->st[parity], slot0, first, got, P->seed, P->spp_begin);
+}
+template <bool COUNT, bool LDS_NODES>
+__device__ __noinline__ void phase_traverse(const DRenderParams* pp, uint32_t parity, uint32_t base, uint32_t count, WorkCounters* wc) {
+    extern __shared__ uint4 lds_nodes[];
+    const DRenderParams* P = uniform_ptr(pp);
+    parity = uniform32(parity);
+    TraverseWork w{};
+    w.lds_nodes = lds_nodes;
+    w.lds_spheres = lds_nodes + 2u * P->sc.n_nodes;
+    w.lds_planars = w.lds_spheres + 2u * P->sc.n_spheres;
+    w.lds_surfaces = P->lds_surfaces;
+    w.base = uniform32(base);
+    w.count = uniform32(count);
+    WorkCounters local;
+    traverse_f32_wave<COUNT, LDS_NODES, false>(P->sc, P->st[parity], P->hits, w, P->tmin, P->tmax0, P->ctl, local);
+    if (COUNT) {
+        wc->nodes += local.nodes;
+        wc->spheres += local.spheres;
+        wc->planars += local.planars;
+        wc->fallbacks += local.fallbacks;
+    }
+}
+__device__ __noinline__ uint32_t phase_shade(const DRenderParams* pp, uint32_t parity, uint32_t base, uint32_t count) {
+    const DRenderParams* P = uniform_ptr(pp);
+    parity = uniform32(parity);
+    base = uniform32(base);
+    count = uniform32(count);
+    return shade_wave(P->sc, P->cam, P->st[parity], P->hits, base, count, P->st[parity ^ 1u], P->seed, P->accum);
+}
+
+template <bool COUNT, bool LDS_NODES>
+__global__ __launch_bounds__(BLOCK, RTX_PERSISTENT_WAVES) void k_render_persistent(const DRenderParams* P) {
+    extern __shared__ uint4 lds_nodes[];
+    if (LDS_NODES) {
+        const DScene& sc = P->sc;
+        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes32);
+        for (uint32_t i = threadIdx.x; i < 2u * sc.n_nodes; i += blockDim.x) lds_nodes[i] = src[i];
+        if (P->lds_surfaces) {
+            uint4* dst_s = lds_nodes + 2u * sc.n_nodes;
+            const uint4* src_s = reinterpret_cast<const uint4*>(sc.spheres);
+            for (uint32_t i = threadIdx.x; i < 2u * sc.n_spheres; i += blockDim.x) dst_s[i] = src_s[i];
+            uint4* dst_p = dst_s + 2u * sc.n_spheres;
+            const uint4* src_p = reinterpret_cast<const uint4*>(sc.planars);
+            for (uint32_t i = threadIdx.x; i < 8u * sc.n_planars; i += blockDim.x) dst_p[i] = src_p[i];
+        }
+        __syncthreads();
+    }
+    const uint32_t wave = uniform32((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (wave >= P->n_sub) return;
+    const uint32_t lane = lane_id();
+    const uint32_t cap = P->cap;
+    const uint32_t base = wave * cap;
+    DRenderCtl* const ctl = P->ctl;
+    const unsigned long long total = ctl->total_paths;
+    WorkCounters wc;
+    unsigned long long n_rays = 0;
+    uint32_t rounds = 0, count = 0, parity = 0;
+    bool exhausted = false;
+    for (;;) {
+        // top up the sub-pool with the next paths of the call
+        if (!exhausted && count < cap) {
+            const uint32_t need = cap - count;
+            unsigned long long first = 0;
+            if (lane == 0) first = atomicAdd(&ctl->next_path[0], (unsigned long long)need);
+            first = uniform64(first);
+            uint32_t got = 0;
+            if (first >= total) {
+                exhausted = true;
+            } else {
+                const unsigned long long rest = total - first;
+                got = rest < need ? (uint32_t)rest : need;
+                exhausted = rest <= need;
+            }
+            if (got) phase_generate(P, parity, base + count, first, got);
+            count += got;
+        }
+        if (count == 0u) break;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        phase_traverse<COUNT, LDS_NODES>(P, parity, base, count, &wc);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        n_rays += count;
+        ++rounds;
+        count = uniform32(phase_shade(P, parity, base, count));
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        parity ^= 1u;
+    }
+    if (COUNT) {   // the work counters are per lane
+        wc.nodes = wave_sum(wc.nodes);
+        wc.spheres = wave_sum(wc.spheres);
+        wc.planars = wave_sum(wc.planars);
+        wc.fallbacks = wave_sum(wc.fallbacks);
+    }
+    if (lane == 0) {
+        atomicAdd(&ctl->rays, n_rays);
+        atomicMax(&ctl->rounds_max, rounds);
+        if (COUNT) {
+            atomicAdd(&ctl->node_visits, wc.nodes);
+            atomicAdd(&ctl->sphere_tests, wc.spheres);
+            atomicAdd(&ctl->planar_tests, wc.planars);
+            atomicAdd(&ctl->box_fallbacks, wc.fallbacks);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- output stage
@@ -883,6 +1077,31 @@ void launch_traverse_f32(const DScene& sc, const DState& rays, const DHits& hits
 void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const DPool& pool, const DState& nxt,
                   uint32_t* counts_out, uint64_t seed, double* accum, hipStream_t s) {
     hipLaunchKernelGGL(k_shade, dim3(grid_for_pool(pool.n_sub)), dim3(BLOCK), 0, s, sc, cam, cur, hits, pool, nxt, counts_out, seed, accum);
+}
+size_t persistent_lds_bytes(const DScene& sc, uint32_t lds_mode) {
+    size_t lds = lds_mode ? (size_t)sc.n_nodes * sizeof(DNode32) : 0;
+    if (lds_mode == 2u) lds += (size_t)sc.n_spheres * sizeof(DSphere) + (size_t)sc.n_planars * sizeof(DPlanar);
+    return lds;
+}
+uint32_t persistent_blocks_per_cu(const DScene& sc, uint32_t lds_mode) {
+    int nb = 0;
+    const size_t lds = persistent_lds_bytes(sc, lds_mode);
+    hipError_t e = lds_mode ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, true>, BLOCK, lds)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, false>, BLOCK, lds);
+    if (e != hipSuccess || nb < 1) nb = 1;
+    return (uint32_t)nb;
+}
+// `params` is device memory; host_params is the same record on the host (for the grid and LDS size).
+void launch_render_persistent(const DRenderParams* params, const DRenderParams& host_params, bool count_work, uint32_t lds_mode, hipStream_t s) {
+    dim3 g(grid_for_pool(host_params.n_sub)), b(BLOCK);
+    const size_t lds = persistent_lds_bytes(host_params.sc, lds_mode);
+    if (lds_mode) {
+        if (count_work) hipLaunchKernelGGL((k_render_persistent<true, true>), g, b, lds, s, params);
+        else hipLaunchKernelGGL((k_render_persistent<false, true>), g, b, lds, s, params);
+    } else {
+        if (count_work) hipLaunchKernelGGL((k_render_persistent<true, false>), g, b, 0, s, params);
+        else hipLaunchKernelGGL((k_render_persistent<false, false>), g, b, 0, s, params);
+    }
 }
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_scale, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, in, n, scale, out);

@@ -213,6 +213,27 @@ def test_single_sample_radiance_bit_exact(rt, oracle, name):
         assert np.array_equal(bits(got + 0.0), bits(want + 0.0)), f"{np.count_nonzero(got != want)} values differ"
 
 
+@pytest.mark.parametrize("path", ["single_launch", "round_loop"])
+@pytest.mark.parametrize("name", ["cover_spheres", "cornell_box", "demo_spheres"])
+def test_render_work_counters_match_oracle(rt, oracle, name, path, monkeypatch):
+    """Both render paths (one persistent launch; generate/traverse/shade rounds) do exactly the
+    oracle's box and surface tests, and produce the same single-sample image."""
+    import torch
+
+    monkeypatch.setenv("RTX_PERSISTENT", "1" if path == "single_launch" else "0")
+    surfaces, cam = S.EXAMPLES[name]()
+    cam = dict(cam, image_width=min(cam["image_width"], 256))
+    dev = rt.Scene(rt.HostBVH(surfaces))
+    orc = oracle.Scene(surfaces)
+    icam, ocam = rt.camera_initialize(cam), oracle.camera_initialize(cam)
+    acc = torch.zeros(icam.image_height, icam.image_width, 3, dtype=torch.float64, device="cuda")
+    st = dev.render_accumulate(icam, 5, 3, 1, acc.data_ptr(), torch.cuda.current_stream().cuda_stream, rt.FLAG_COUNT_WORK)
+    want, ctr = orc.render(ocam, 5, 3, 1, iterative=True)
+    assert [st.rays, st.paths, st.node_visits, st.sphere_tests, st.planar_tests] == \
+           [ctr.rays, ctr.paths, ctr.node_visits, ctr.sphere_tests, ctr.planar_tests]
+    assert np.array_equal(bits(acc.cpu().numpy() + 0.0), bits(want + 0.0))
+
+
 @pytest.mark.parametrize("name", ["cover_spheres", "cornell_box", "demo_spheres", "simple_light"])
 def test_radiance_matches_recursive_ray_color(rt, oracle, name):
     """Against ray_color exactly as the reference writes it (recursive): only
