@@ -515,7 +515,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     if (sc->f32_ok && !(flags & (RTX_FLAG_EXACT_DIVIDE | RTX_FLAG_F64_FILTER | RTX_FLAG_TIME_KERNELS)) && env_u32("RTX_PERSISTENT", 1) == 1u) {
         PathPool* pp = sc->lane(0);
         const uint32_t mode = lds_mode_for(sc, flags);
-        const uint32_t waves = sc->n_cus * persistent_blocks_per_cu(sc->d, mode) * 4u;   // exactly what is resident at once
+        const uint32_t waves = sc->n_cus * persistent_waves_per_cu(sc->d, mode);   // exactly what is resident at once
         const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 23);   // 2048 slots per wave: a wave's round ends with a drain, so long rounds pay
         const uint64_t need = total < want ? total : want;
         uint32_t n_sub;

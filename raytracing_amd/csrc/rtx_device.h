@@ -290,6 +290,24 @@ __device__ __forceinline__ V3 random_unit(PathRng& rng) {
         if (1e-160 < lensq && lensq <= 1.0) return candidate / sqrt(lensq);
     }
 }
+// The same two samplers on a bare draw index (which must be even: a sampling event starts on a block
+// boundary), for callers that keep no PathRng: candidate of one trial, and the first uniform of a block.
+__device__ __forceinline__ V3 random_unit_candidate(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk) {
+    uint32_t o[4];
+    philox4x32_10(pixel, sample, blk, 0u, k0, k1, o);
+    const uint64_t w0 = ((uint64_t)o[1] << 32) | o[0];
+    const uint64_t w1 = ((uint64_t)o[3] << 32) | o[2];
+    const double a = (double)(w0 >> 22) * 0x1.0p-42;
+    const double b = (double)(w1 >> 22) * 0x1.0p-42;
+    const double c = (double)(((w0 & 0x3FFFFFull) << 20) | (w1 & 0xFFFFFull)) * 0x1.0p-42;
+    return v3(a * 2.0 + -1.0, b * 2.0 + -1.0, c * 2.0 + -1.0);
+}
+__device__ __forceinline__ double first_uniform_of_block(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk) {
+    uint32_t o[4];
+    philox4x32_10(pixel, sample, blk, 0u, k0, k1, o);
+    const uint64_t w0 = ((uint64_t)o[1] << 32) | o[0];
+    return (double)(w0 >> 11) * 0x1.0p-53;
+}
 // src/vector.rs:83-95
 __device__ __forceinline__ V3 random_in_unit_disk(PathRng& rng) {
     for (;;) {

@@ -39,7 +39,10 @@ constexpr uint32_t MAX_BLOCK_WAVES = TRAVERSE_LDS_BLOCK / 64 > BLOCK / 64 ? TRAV
 #define RTX_SHADE_WAVES 4
 #endif
 #ifndef RTX_PERSISTENT_WAVES
-#define RTX_PERSISTENT_WAVES 4
+#define RTX_PERSISTENT_WAVES 5
+#endif
+#ifndef RTX_PERSISTENT_BLOCK
+#define RTX_PERSISTENT_BLOCK 256
 #endif
 #ifndef RTX_REFILL_AT
 #define RTX_REFILL_AT 32
@@ -776,14 +779,24 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
                 }
 
                 // Material::scatter, material.rs:20-33
-                PathRng rng(seed, pixel, sample, draw0);
-                rng.begin_event();
+                // the scatter call is one sampling event: it starts on a block boundary of the path's stream
+                const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+                uint32_t draw_ev = (draw0 + 1u) & ~1u;
                 bool scattered = false;
                 V3 att = v3(1.0, 1.0, 1.0);
                 if (mkind <= 1u) {
                     // Lambertian and Metal both start with Vector3::random_unit()
                     // (material.rs:62, :86); one shared rejection loop for the wave
-                    const V3 ru = random_unit(rng);
+                    V3 cand;
+                    double lensq;
+                    uint32_t blk = draw_ev >> 1;
+                    do {   // Vector3::random_unit, src/vector.rs:59-81: one Philox block per trial
+                        cand = random_unit_candidate(k0, k1, pixel, sample, blk);
+                        ++blk;
+                        lensq = length_squared(cand);
+                    } while (!(1e-160 < lensq && lensq <= 1.0));
+                    const V3 ru = cand / sqrt(lensq);
+                    draw_ev = blk << 1;
                     att = rgb;
                     if (mkind == 0u) {        // lambertian, material.rs:61-73
                         V3 direction = n + ru;
@@ -803,14 +816,17 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
                     double cos_theta = clampd(dot(-r_in, n), -1.0, 1.0);
                     double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
                     bool refl = eta * sin_theta > 1.0;
-                    if (!refl) refl = reflectance(cos_theta, eta) > rng.next();   // no draw on total internal reflection
+                    if (!refl) {   // no draw on total internal reflection
+                        refl = reflectance(cos_theta, eta) > first_uniform_of_block(k0, k1, pixel, sample, draw_ev >> 1);
+                        ++draw_ev;
+                    }
                     nd = refl ? reflect(r_in, n) : refract(r_in, n, eta);
                     scattered = true;
                 }
                 depth = depth0 + 1u;
                 if (scattered && depth < cam.max_depth) {
                     beta = beta * att;
-                    draw = rng.draw;
+                    draw = draw_ev;
                     alive = true;
                 }
             }
@@ -862,13 +878,40 @@ __global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCa
 __device__ __forceinline__ const DRenderParams* uniform_ptr(const DRenderParams* p) {
     return (const DRenderParams*)uniform64((unsigned long long)p);
 }
+// Copies of the parameter record's tables with every pointer in scalar registers.  Loaded through the
+// (uniform) parameter pointer they would otherwise sit in vector registers, two per pointer, and spill.
+template <class T>
+__device__ __forceinline__ T* uniform_p(T* p) { return (T*)uniform64((unsigned long long)p); }
+__device__ __forceinline__ DState uniform_state(const DState& s) {
+    DState u;
+    u.ox = uniform_p(s.ox); u.oy = uniform_p(s.oy); u.oz = uniform_p(s.oz);
+    u.dx = uniform_p(s.dx); u.dy = uniform_p(s.dy); u.dz = uniform_p(s.dz);
+    u.bx = uniform_p(s.bx); u.by = uniform_p(s.by); u.bz = uniform_p(s.bz);
+    u.pixel = uniform_p(s.pixel); u.sample = uniform_p(s.sample); u.draw = uniform_p(s.draw); u.depth = uniform_p(s.depth);
+    return u;
+}
+__device__ __forceinline__ DHits uniform_hits(const DHits& h) {
+    DHits u;
+    u.prim = uniform_p(h.prim);
+    u.t = uniform_p(h.t);
+    return u;
+}
+__device__ __forceinline__ DScene uniform_scene(const DScene& s) {
+    DScene u = s;
+    u.nodes = uniform_p(s.nodes); u.spheres = uniform_p(s.spheres); u.planars = uniform_p(s.planars);
+    u.prims = uniform_p(s.prims); u.materials = uniform_p(s.materials); u.nodes32 = uniform_p(s.nodes32);
+    u.boxes64 = uniform_p(s.boxes64); u.shade_recs = uniform_p(s.shade_recs); u.rec_user_id = uniform_p(s.rec_user_id);
+    u.n_nodes = uniform32(s.n_nodes); u.n_prims = uniform32(s.n_prims); u.filter_ok = uniform32(s.filter_ok);
+    u.n_spheres = uniform32(s.n_spheres); u.n_planars = uniform32(s.n_planars);
+    return u;
+}
 __device__ __noinline__ void phase_generate(const DRenderParams* pp, uint32_t parity, uint32_t slot0, unsigned long long first, uint32_t got) {
     const DRenderParams* P = uniform_ptr(pp);
     parity = uniform32(parity);
     slot0 = uniform32(slot0);
     got = uniform32(got);
     first = uniform64(first);
-    generate_wave(P->cam, P->st[parity], slot0, first, got, P->seed, P->spp_begin);
+    generate_wave(P->cam, uniform_state(P->st[parity]), slot0, first, got, uniform64(P->seed), uniform32(P->spp_begin));
 }
 template <bool COUNT, bool LDS_NODES>
 __device__ __noinline__ void phase_traverse(const DRenderParams* pp, uint32_t parity, uint32_t base, uint32_t count, WorkCounters* wc) {
@@ -883,7 +926,9 @@ __device__ __noinline__ void phase_traverse(const DRenderParams* pp, uint32_t pa
     w.base = uniform32(base);
     w.count = uniform32(count);
     WorkCounters local;
-    traverse_f32_wave<COUNT, LDS_NODES, false>(P->sc, P->st[parity], P->hits, w, P->tmin, P->tmax0, P->ctl, local);
+    traverse_f32_wave<COUNT, LDS_NODES, false>(uniform_scene(P->sc), uniform_state(P->st[parity]), uniform_hits(P->hits), w,
+                                               __longlong_as_double((long long)uniform64((unsigned long long)__double_as_longlong(P->tmin))),
+                                               __longlong_as_double((long long)uniform64((unsigned long long)__double_as_longlong(P->tmax0))), uniform_p(P->ctl), local);
     if (COUNT) {
         wc->nodes += local.nodes;
         wc->spheres += local.spheres;
@@ -896,11 +941,12 @@ __device__ __noinline__ uint32_t phase_shade(const DRenderParams* pp, uint32_t p
     parity = uniform32(parity);
     base = uniform32(base);
     count = uniform32(count);
-    return shade_wave(P->sc, P->cam, P->st[parity], P->hits, base, count, P->st[parity ^ 1u], P->seed, P->accum);
+    return shade_wave(uniform_scene(P->sc), P->cam, uniform_state(P->st[parity]), uniform_hits(P->hits), base, count,
+                      uniform_state(P->st[parity ^ 1u]), uniform64(P->seed), uniform_p(P->accum));
 }
 
 template <bool COUNT, bool LDS_NODES>
-__global__ __launch_bounds__(BLOCK, RTX_PERSISTENT_WAVES) void k_render_persistent(const DRenderParams* P) {
+__global__ __launch_bounds__(RTX_PERSISTENT_BLOCK, RTX_PERSISTENT_WAVES) void k_render_persistent(const DRenderParams* P) {
     extern __shared__ uint4 lds_nodes[];
     if (LDS_NODES) {
         const DScene& sc = P->sc;
@@ -1083,17 +1129,18 @@ size_t persistent_lds_bytes(const DScene& sc, uint32_t lds_mode) {
     if (lds_mode == 2u) lds += (size_t)sc.n_spheres * sizeof(DSphere) + (size_t)sc.n_planars * sizeof(DPlanar);
     return lds;
 }
-uint32_t persistent_blocks_per_cu(const DScene& sc, uint32_t lds_mode) {
+uint32_t persistent_waves_per_cu(const DScene& sc, uint32_t lds_mode) {
     int nb = 0;
     const size_t lds = persistent_lds_bytes(sc, lds_mode);
-    hipError_t e = lds_mode ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, true>, BLOCK, lds)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, false>, BLOCK, lds);
+    hipError_t e = lds_mode ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, true>, RTX_PERSISTENT_BLOCK, lds)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, false>, RTX_PERSISTENT_BLOCK, lds);
     if (e != hipSuccess || nb < 1) nb = 1;
-    return (uint32_t)nb;
+    return (uint32_t)nb * (RTX_PERSISTENT_BLOCK / 64);   // waves
 }
 // `params` is device memory; host_params is the same record on the host (for the grid and LDS size).
 void launch_render_persistent(const DRenderParams* params, const DRenderParams& host_params, bool count_work, uint32_t lds_mode, hipStream_t s) {
-    dim3 g(grid_for_pool(host_params.n_sub)), b(BLOCK);
+    const uint32_t block_waves = RTX_PERSISTENT_BLOCK / 64;
+    dim3 g((host_params.n_sub + block_waves - 1) / block_waves), b(RTX_PERSISTENT_BLOCK);
     const size_t lds = persistent_lds_bytes(host_params.sc, lds_mode);
     if (lds_mode) {
         if (count_work) hipLaunchKernelGGL((k_render_persistent<true, true>), g, b, lds, s, params);
