@@ -696,6 +696,17 @@ __device__ __forceinline__ double reflectance(double cos_theta, double refractio
     return r0 + (1.0 - r0) * x5;
 }
 
+// Sphere u,v (geometry.rs:236-240), from the world-space point as the reference has it.  Out of line: no
+// example scene puts UVGradient on a sphere, and inlined the acos/atan2 polynomials keep two dozen
+// registers of coefficients alive through the whole shade loop.
+__device__ __noinline__ void sphere_uv(double px, double py, double pz, double& alpha, double& beta_uv) {
+    const double PI = 3.14159265358979323846264338327950288;
+    const double theta = acos(-py);
+    const double phi = atan2(-pz, px) + PI;
+    alpha = phi / (2.0 * PI);
+    beta_uv = theta / PI;
+}
+
 // One step of ray_color (src/camera.rs:184-208) in its iterative form:
 //   miss            -> add beta * background, path ends
 //   hit             -> add beta * emitted; scatter ? (beta *= attenuation, new ray) : path ends
@@ -747,13 +758,7 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
                 double alpha = 0.0, beta_uv = 0.0;
                 if (!planar) {
                     outward = (p - rec_a) * r1.y;   // (p - center) / radius
-                    if (mkind == 4u) {   // u,v only feed UVGradient (geometry.rs:236-240)
-                        const double PI = 3.14159265358979323846264338327950288;
-                        double theta = acos(-p.y);
-                        double phi = atan2(-p.z, p.x) + PI;
-                        alpha = phi / (2.0 * PI);
-                        beta_uv = theta / PI;
-                    }
+                    if (mkind == 4u) sphere_uv(p.x, p.y, p.z, alpha, beta_uv);   // u,v only feed UVGradient
                 } else {
                     outward = rec_a;
                     if (mkind == 4u) {
