@@ -107,7 +107,7 @@ struct PathPool {
         return RTX_OK;
     }
     int ensure_capacity(size_t n) {
-        HIP_TRY(ctl.resize(4));   // the records behind the first are scratch for instrumented debug builds
+        HIP_TRY(ctl.resize(8));   // the records behind the first are scratch for instrumented debug builds
         if (n <= capacity) return RTX_OK;
         HIP_TRY(buf_f64.resize(19 * n));
         HIP_TRY(buf_u32.resize(9 * n));
@@ -543,6 +543,9 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         P.spp_begin = spp_begin;
         P.lds_surfaces = mode == 2u ? 1u : 0u;
         HIP_TRY(hipMemcpyAsync(pp->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
+#ifdef RTX_PROFILE_PHASES
+        HIP_TRY(hipMemsetAsync(pp->ctl.p + 1, 0, 7 * sizeof(DRenderCtl), s));
+#endif
         HIP_TRY(hipMemcpyAsync(pp->params.p, &P, sizeof(P), hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(sc->ev0, s));
         launch_render_persistent(pp->params.p, P, (flags & RTX_FLAG_COUNT_WORK) != 0, mode, s);
@@ -563,6 +566,15 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
             stats->box_fallbacks = back.box_fallbacks;
             stats->iterations = back.rounds_max;
         }
+#ifdef RTX_PROFILE_PHASES
+        {
+            unsigned long long pr[10];
+            (void)hipMemcpy(pr, reinterpret_cast<unsigned long long*>(pp->ctl.p + 1) + 16, sizeof(pr), hipMemcpyDeviceToHost);
+            if (pr[7])
+                std::fprintf(stderr, "PHASES per wave (cycles): generate %.0f traverse %.0f shade %.0f, life %.0f (longest %llu), %llu waves\n",
+                             (double)pr[0] / pr[7], (double)pr[1] / pr[7], (double)pr[2] / pr[7], (double)pr[6] / pr[7], pr[9], pr[7]);
+        }
+#endif
         return RTX_OK;
     }
 

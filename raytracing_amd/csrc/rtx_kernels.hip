@@ -696,6 +696,71 @@ __device__ __forceinline__ double reflectance(double cos_theta, double refractio
     return r0 + (1.0 - r0) * x5;
 }
 
+// Vector3::random_unit() (src/vector.rs:59-81) for the lanes with `need`, as a
+// wave.  The reference's loop accepts 52 % of its candidates, so 64 lanes
+// looping in lockstep wait for the unluckiest one (6-7 rounds for 1.9 useful
+// trials).  Here every lane first tries its own trial 0; after that the lanes
+// between two unresolved lanes all work for the upper one, each on a
+// different one of its next trials, and the lowest accepted trial wins.  Trial
+// k of a ray is Philox block blk0 + k of its stream whichever lane computes
+// it, so the accepted candidate and the number of trials are exactly those of
+// the sequential loop.  Must be called by all 64 lanes.  Returns the accepted
+// candidate (not normalised) and the number of trials used.
+__device__ __forceinline__ void random_unit_wave(bool need, uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk0,
+                                                 V3& cand, uint32_t& used) {
+    const uint32_t lane = lane_id();
+    cand = v3(1.0, 0.0, 0.0);
+    used = 0u;
+    uint32_t tried = 0;   // trials of this lane's own ray that have failed so far
+    bool unresolved = need;
+    if (need) {
+        const V3 c = random_unit_candidate(k0, k1, pixel, sample, blk0);
+        const double l = length_squared(c);
+        tried = 1u;
+        if (1e-160 < l && l <= 1.0) {
+            cand = c;
+            used = 1u;
+            unresolved = false;
+        }
+    }
+    unsigned long long U = ballot64(unresolved);
+    while (U != 0ull) {
+        // the unresolved lane at or above this one, and how many lanes lie between it and the unresolved lane below
+        const unsigned long long at_or_above = U >> lane;
+        const bool helping = at_or_above != 0ull;
+        const uint32_t target = helping ? lane + (uint32_t)__builtin_ctzll(at_or_above) : lane;
+        const unsigned long long below = U & ((1ull << lane) - 1ull);                      // unresolved lanes under this one
+        const uint32_t first_helper = below ? 64u - (uint32_t)__builtin_clzll(below) : 0u;   // lane after the unresolved lane below
+        const uint32_t q = lane - first_helper;                                              // this lane's trial offset for the target
+        const uint32_t t_pixel = __shfl(pixel, (int)target, 64), t_sample = __shfl(sample, (int)target, 64);
+        const uint32_t t_blk = __shfl(blk0 + tried, (int)target, 64);
+        bool ok = false;
+        V3 c = v3(0.0, 0.0, 0.0);
+        if (helping) {
+            c = random_unit_candidate(k0, k1, t_pixel, t_sample, t_blk + q);
+            const double l = length_squared(c);
+            ok = 1e-160 < l && l <= 1.0;
+        }
+        const unsigned long long okmask = ballot64(ok);
+        // an unresolved lane looks at its helpers: lanes first_helper .. lane
+        const unsigned long long mine = unresolved ? (okmask >> first_helper) & (~0ull >> (63u - (lane - first_helper))) : 0ull;
+        const bool got = mine != 0ull;
+        const uint32_t win_q = got ? (uint32_t)__builtin_ctzll(mine) : 0u;
+        const int src = (int)(first_helper + win_q);
+        const double cx = __shfl(c.x, src, 64), cy = __shfl(c.y, src, 64), cz = __shfl(c.z, src, 64);
+        if (unresolved) {
+            if (got) {
+                cand = v3(cx, cy, cz);
+                used = tried + win_q + 1u;
+                unresolved = false;
+            } else {
+                tried += lane - first_helper + 1u;   // all of this round's helpers failed
+            }
+        }
+        U = ballot64(unresolved);
+    }
+}
+
 // Sphere u,v (geometry.rs:236-240), from the world-space point as the reference has it.  Out of line: no
 // example scene puts UVGradient on a sphere, and inlined the acos/atan2 polynomials keep two dozen
 // registers of coefficients alive through the whole shade loop.
@@ -727,18 +792,30 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
         bool alive = false;
         V3 p = v3(0, 0, 0), nd = v3(0, 0, 0), beta = v3(0, 0, 0);
         uint32_t pixel = 0, sample = 0, draw = 0, depth = 0;
+        // every load that does not depend on another is issued here, up front;
+        // the surface record is the only dependent round trip
+        uint32_t handle = NONE, draw0 = 0, depth0 = 0;
+        double t = 0.0;
+        V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
         if (off < count) {
-            // every load that does not depend on another is issued here, up
-            // front; the surface record is the only dependent round trip
-            const uint32_t handle = hits.prim[i];
-            const double t = hits.t[i];
-            const V3 o = v3(cur.ox[i], cur.oy[i], cur.oz[i]);
-            const V3 d = v3(cur.dx[i], cur.dy[i], cur.dz[i]);
+            handle = hits.prim[i];
+            t = hits.t[i];
+            o = v3(cur.ox[i], cur.oy[i], cur.oz[i]);
+            d = v3(cur.dx[i], cur.dy[i], cur.dz[i]);
             beta = v3(cur.bx[i], cur.by[i], cur.bz[i]);
             pixel = cur.pixel[i];
             sample = cur.sample[i];
-            const uint32_t draw0 = cur.draw[i];
-            const uint32_t depth0 = cur.depth[i];
+            draw0 = cur.draw[i];
+            depth0 = cur.depth[i];
+        }
+        // Material::scatter (material.rs:20-33) is one sampling event: it starts on a block boundary of the path's
+        // stream.  Lambertian and Metal both start with Vector3::random_unit() (material.rs:62, :86), run here for the wave.
+        const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+        uint32_t draw_ev = (draw0 + 1u) & ~1u;
+        V3 ru_cand;
+        uint32_t ru_trials;
+        random_unit_wave(off < count && handle != NONE && code_mat(handle) <= 1u, k0, k1, pixel, sample, draw_ev >> 1, ru_cand, ru_trials);
+        if (off < count) {
             V3 radiance = v3(0.0, 0.0, 0.0);
             bool add = false;
             if (handle == NONE) {
@@ -784,24 +861,11 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
                 }
 
                 // Material::scatter, material.rs:20-33
-                // the scatter call is one sampling event: it starts on a block boundary of the path's stream
-                const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-                uint32_t draw_ev = (draw0 + 1u) & ~1u;
                 bool scattered = false;
                 V3 att = v3(1.0, 1.0, 1.0);
                 if (mkind <= 1u) {
-                    // Lambertian and Metal both start with Vector3::random_unit()
-                    // (material.rs:62, :86); one shared rejection loop for the wave
-                    V3 cand;
-                    double lensq;
-                    uint32_t blk = draw_ev >> 1;
-                    do {   // Vector3::random_unit, src/vector.rs:59-81: one Philox block per trial
-                        cand = random_unit_candidate(k0, k1, pixel, sample, blk);
-                        ++blk;
-                        lensq = length_squared(cand);
-                    } while (!(1e-160 < lensq && lensq <= 1.0));
-                    const V3 ru = cand / sqrt(lensq);
-                    draw_ev = blk << 1;
+                    const V3 ru = ru_cand / sqrt(length_squared(ru_cand));
+                    draw_ev += 2u * ru_trials;
                     att = rgb;
                     if (mkind == 0u) {        // lambertian, material.rs:61-73
                         V3 direction = n + ru;
@@ -968,9 +1032,10 @@ __global__ __launch_bounds__(RTX_PERSISTENT_BLOCK, RTX_PERSISTENT_WAVES) void k_
         __syncthreads();
     }
     const uint32_t wave = uniform32((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (wave >= P->n_sub) return;
+    const uint32_t n_sub = uniform32(P->n_sub);
+    if (wave >= n_sub) return;
     const uint32_t lane = lane_id();
-    const uint32_t cap = P->cap;
+    const uint32_t cap = uniform32(P->cap);
     const uint32_t base = wave * cap;
     DRenderCtl* const ctl = P->ctl;
     const unsigned long long total = ctl->total_paths;
@@ -978,6 +1043,13 @@ __global__ __launch_bounds__(RTX_PERSISTENT_BLOCK, RTX_PERSISTENT_WAVES) void k_
     unsigned long long n_rays = 0;
     uint32_t rounds = 0, count = 0, parity = 0;
     bool exhausted = false;
+#ifdef RTX_PROFILE_PHASES
+    long long pp_gen = 0, pp_trav = 0, pp_shade = 0, pp_mark = clock64();
+    const long long pp_begin = pp_mark;
+#define PP(acc) do { const long long now_ = clock64(); acc += now_ - pp_mark; pp_mark = now_; } while (0)
+#else
+#define PP(acc) do {} while (0)
+#endif
     for (;;) {
         // top up the sub-pool with the next paths of the call
         if (!exhausted && count < cap) {
@@ -998,14 +1070,28 @@ __global__ __launch_bounds__(RTX_PERSISTENT_BLOCK, RTX_PERSISTENT_WAVES) void k_
         }
         if (count == 0u) break;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        PP(pp_gen);
         phase_traverse<COUNT, LDS_NODES>(P, parity, base, count, &wc);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        PP(pp_trav);
         n_rays += count;
         ++rounds;
         count = uniform32(phase_shade(P, parity, base, count));
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        PP(pp_shade);
         parity ^= 1u;
     }
+#ifdef RTX_PROFILE_PHASES
+    if (lane == 0) {
+        unsigned long long* pr = reinterpret_cast<unsigned long long*>(ctl + 1) + 16;   // debug area behind the control block
+        atomicAdd(pr + 0, (unsigned long long)pp_gen);
+        atomicAdd(pr + 1, (unsigned long long)pp_trav);
+        atomicAdd(pr + 2, (unsigned long long)pp_shade);
+        atomicAdd(pr + 6, (unsigned long long)(clock64() - pp_begin));
+        atomicAdd(pr + 7, 1ull);
+        atomicMax(pr + 9, (unsigned long long)(clock64() - pp_begin));
+    }
+#endif
     if (COUNT) {   // the work counters are per lane
         wc.nodes = wave_sum(wc.nodes);
         wc.spheres = wave_sum(wc.spheres);
