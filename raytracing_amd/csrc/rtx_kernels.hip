@@ -945,12 +945,18 @@ __global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCa
 // register allocation (the kernel's register count is the largest of them, not
 // their sum), and a call per phase per round costs nothing against the phase.
 __device__ __forceinline__ const DRenderParams* uniform_ptr(const DRenderParams* p) {
-    return (const DRenderParams*)uniform64((unsigned long long)p);
+    typedef __attribute__((address_space(1))) const DRenderParams* global_ptr;
+    return (const DRenderParams*)(global_ptr)uniform64((unsigned long long)p);
 }
 // Copies of the parameter record's tables with every pointer in scalar registers.  Loaded through the
 // (uniform) parameter pointer they would otherwise sit in vector registers, two per pointer, and spill.
+// (The round trip through the global address space tells the compiler what a pointer read from memory cannot:
+// that it points to device memory, so accesses become global_* with a scalar base instead of flat_*.)
 template <class T>
-__device__ __forceinline__ T* uniform_p(T* p) { return (T*)uniform64((unsigned long long)p); }
+__device__ __forceinline__ T* uniform_p(T* p) {
+    typedef __attribute__((address_space(1))) T* global_ptr;
+    return (T*)(global_ptr)uniform64((unsigned long long)p);
+}
 __device__ __forceinline__ DState uniform_state(const DState& s) {
     DState u;
     u.ox = uniform_p(s.ox); u.oy = uniform_p(s.oy); u.oz = uniform_p(s.oz);
