@@ -111,6 +111,19 @@ typedef struct rtx_stats {
 
 typedef struct rtx_scene rtx_scene;
 
+/* PartitionBy / SAHBucketStrategy, src/bvh/mod.rs:13-34 */
+enum rtx_partition { RTX_BISECT = 0, RTX_MIDPOINT = 1, RTX_SAH_EQUAL_SIZE = 2, RTX_SAH_PER_SURFACE = 3 };
+
+/* Timers and sizes of one rtx_bvh_build call (the reference has one
+ * wall-clock timer around BVH::from_slice, src/runner.rs:26-29). */
+typedef struct rtx_build_stats {
+    uint32_t levels;        /* passes over the surfaces == depth of the tree */
+    uint32_t n_nodes;
+    double   ms_sort;       /* upload of the boxes + the three initial sorts, HIP events */
+    double   ms_levels;     /* all levels + the leaf pass */
+    uint64_t device_bytes;  /* HBM held while building */
+} rtx_build_stats;
+
 /* flags for rtx_render_accumulate / rtx_trace_closest */
 #define RTX_FLAG_COUNT_WORK   1u  /* fill node_visits / *_tests (slower) */
 #define RTX_FLAG_TIME_KERNELS 2u  /* render with the round loop (generate / traverse / shade launches) and time every launch with HIP events */
@@ -130,6 +143,23 @@ int rtx_device_count(void);
  * the call returns. */
 int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out);
 void rtx_scene_destroy(rtx_scene* scene);
+
+/* BVH::from_slice(surfaces, &partition_by) on the current HIP device
+ * (src/bvh/mod.rs:76-131) for RTX_MIDPOINT, RTX_SAH_EQUAL_SIZE(buckets) and
+ * RTX_SAH_PER_SURFACE (src/bvh/partition.rs:70-266); the tree is the
+ * reference's, node for node.  RTX_BISECT is refused: it rests on
+ * sort_unstable_by (partition.rs:58-68), whose order of equal keys the
+ * reference leaves open.
+ * leaf_boxes: host, [n][6] = Surface::bounding_box of every surface
+ * (min x,y,z, max x,y,z).  Outputs, host: leaf_order[n] = index of the
+ * surface that is the i-th leaf in pre-order (the order `surfaces` is left
+ * in); node tables of 2n-1 nodes in the layout of rtx_scene_desc with
+ * node_prim = i for that leaf.  Fails with RTX_ERR_BUILD where the reference
+ * panics or never returns: "No valid splitting plane" (partition.rs:219), a
+ * partition with an empty side.  stats may be NULL. */
+int rtx_bvh_build(const double* leaf_boxes, uint32_t n, int strategy, uint32_t buckets,
+                  uint32_t* leaf_order, double* node_bmin, double* node_bmax,
+                  uint32_t* node_right, uint32_t* node_prim, rtx_build_stats* stats);
 
 /* Closest hit for n rays.  Replaces n calls of `impl Hittable for BVH::hit`
  * (src/bvh/mod.rs:134-174) with ray_t = [tmin, tmax].  org/dir: host, [n][3].

@@ -19,8 +19,9 @@
 extern "C" {
 #endif
 
-/* PartitionBy / SAHBucketStrategy, src/bvh/mod.rs:13-34 */
-enum rth_partition { RTH_BISECT = 0, RTH_MIDPOINT = 1, RTH_SAH_EQUAL_SIZE = 2, RTH_SAH_PER_SURFACE = 3 };
+/* PartitionBy / SAHBucketStrategy, src/bvh/mod.rs:13-34: the values of enum rtx_partition */
+enum rth_partition { RTH_BISECT = RTX_BISECT, RTH_MIDPOINT = RTX_MIDPOINT, RTH_SAH_EQUAL_SIZE = RTX_SAH_EQUAL_SIZE,
+                     RTH_SAH_PER_SURFACE = RTX_SAH_PER_SURFACE };
 
 /* One Surface { geometry, material } as a caller of the reference
  * constructs it (src/surface.rs:15-24); derived plane fields are computed
@@ -61,6 +62,11 @@ const char* rth_last_error(void);
  * (src/bvh/partition.rs:219), a negative sphere radius
  * (src/geometry.rs:56-62), a partition with an empty side. */
 int rth_bvh_build(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, rth_bvh** out);
+/* The same tree with the partitioning done on the current HIP device
+ * (rtx_bvh_build); the surfaces' boxes and the flattened tables are made on
+ * the host.  stats may be NULL. */
+int rth_bvh_build_device(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, rth_bvh** out,
+                         rtx_build_stats* stats);
 /* Fills `out` with pointers into the BVH's tables (valid until rth_bvh_destroy). */
 void rth_bvh_desc(const rth_bvh* bvh, rtx_scene_desc* out);
 void rth_bvh_destroy(rth_bvh* bvh);
@@ -73,6 +79,9 @@ int rth_camera_initialize(const rtx_camera_config* cfg, rtx_camera* out);
  * linear image to out_rgb ([H][W][3], may be NULL). */
 int rth_run(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, const rtx_camera_config* cfg,
             uint64_t seed, const char* ppm_path, double* out_rgb);
+/* rth_run with the BVH built by rth_bvh_build_device */
+int rth_run_device_build(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, const rtx_camera_config* cfg,
+                         uint64_t seed, const char* ppm_path, double* out_rgb);
 
 #ifdef __cplusplus
 }

@@ -92,12 +92,22 @@ class Stats(C.Structure):  # rtx_stats
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class BuildStats(C.Structure):  # rtx_build_stats
+    _fields_ = [
+        ("levels", C.c_uint32), ("n_nodes", C.c_uint32), ("ms_sort", C.c_double), ("ms_levels", C.c_double),
+        ("device_bytes", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 # every symbol include/rtx.h and include/rtx_host.h declare
 ABI_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_trace_closest",
     "rtx_primary_rays", "rtx_render_accumulate", "rtx_scale", "rtx_quantize", "rtx_render", "rtx_selftest_math",
-    "rtx_selftest_rng",
-    "rth_last_error", "rth_bvh_build", "rth_bvh_desc", "rth_bvh_destroy", "rth_camera_initialize", "rth_run",
+    "rtx_selftest_rng", "rtx_bvh_build",
+    "rth_last_error", "rth_bvh_build", "rth_bvh_build_device", "rth_run_device_build", "rth_bvh_desc", "rth_bvh_destroy", "rth_camera_initialize", "rth_run",
 ]
 
 _lib.rtx_last_error.restype = C.c_char_p
@@ -115,6 +125,9 @@ _lib.rtx_render.argtypes = [C.c_void_p, _p(Camera), C.c_uint64, C.c_uint32, _dp,
 _lib.rtx_selftest_math.argtypes = [C.c_int, _dp, _dp, C.c_uint64, _dp]
 _lib.rtx_selftest_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _dp]
 _lib.rth_bvh_build.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, _p(C.c_void_p)]
+_lib.rth_bvh_build_device.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, _p(C.c_void_p), _p(BuildStats)]
+_lib.rtx_bvh_build.argtypes = [_dp, C.c_uint32, C.c_int, C.c_uint32, _u32p, _dp, _dp, _u32p, _u32p, _p(BuildStats)]
+_lib.rth_run_device_build.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, _p(CameraConfig), C.c_uint64, C.c_char_p, _dp]
 _lib.rth_bvh_desc.argtypes = [C.c_void_p, _p(SceneDesc)]
 _lib.rth_bvh_desc.restype = None
 _lib.rth_bvh_destroy.argtypes = [C.c_void_p]
@@ -166,13 +179,34 @@ def camera_initialize(cam):
     return out
 
 
-class HostBVH:
-    """``BVH::from_slice`` on the CPU (the product's own builder)."""
+def bvh_build_device(leaf_boxes, strategy=SAH_PER_SURFACE, buckets=0):
+    """``rtx_bvh_build``: leaf boxes [n, 6] -> (leaf_order[n], bmin[3, 2n-1], bmax[3, 2n-1], right, prim, BuildStats)."""
+    boxes = _f64(leaf_boxes).reshape(-1, 6)
+    n = len(boxes)
+    nn = max(2 * n - 1, 0)
+    order = np.zeros(n, np.uint32)
+    bmin, bmax = np.zeros((3, nn)), np.zeros((3, nn))
+    right, prim = np.zeros(nn, np.uint32), np.zeros(nn, np.uint32)
+    st = BuildStats()
+    _check(_lib.rtx_bvh_build(_ptr(boxes, _dp), n, strategy, buckets, _ptr(order, _u32p), _ptr(bmin, _dp), _ptr(bmax, _dp),
+                              _ptr(right, _u32p), _ptr(prim, _u32p), C.byref(st)))
+    return order, bmin, bmax, right, prim, st
 
-    def __init__(self, surfaces, strategy=SAH_PER_SURFACE, buckets=0):
+
+class HostBVH:
+    """``BVH::from_slice``: on the CPU (the product's host builder), or with ``device=True`` partitioned by the
+    device builder (``rtx_bvh_build``); both give the reference's tree."""
+
+    def __init__(self, surfaces, strategy=SAH_PER_SURFACE, buckets=0, device=False):
         surfaces = np.ascontiguousarray(surfaces, dtype=SURFACE_DTYPE)
         self._h = C.c_void_p()
-        _check(_lib.rth_bvh_build(surfaces.ctypes.data_as(C.c_void_p), len(surfaces), strategy, buckets, C.byref(self._h)), host=True)
+        self.build_stats = None
+        if device:
+            self.build_stats = BuildStats()
+            _check(_lib.rth_bvh_build_device(surfaces.ctypes.data_as(C.c_void_p), len(surfaces), strategy, buckets, C.byref(self._h),
+                                             C.byref(self.build_stats)), host=True)
+        else:
+            _check(_lib.rth_bvh_build(surfaces.ctypes.data_as(C.c_void_p), len(surfaces), strategy, buckets, C.byref(self._h)), host=True)
         self.desc = SceneDesc()
         _lib.rth_bvh_desc(self._h, C.byref(self.desc))
 

@@ -749,6 +749,30 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     return status;
 }
 
+int rtx_bvh_build(const double* leaf_boxes, uint32_t n, int strategy, uint32_t buckets, uint32_t* leaf_order, double* node_bmin,
+                  double* node_bmax, uint32_t* node_right, uint32_t* node_prim, rtx_build_stats* stats) {
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n == 0) return RTX_OK;   // an empty scene has an empty tree (src/bvh/mod.rs:84-86)
+    if (!leaf_boxes || !leaf_order || !node_bmin || !node_bmax || !node_right || !node_prim)
+        return fail(RTX_ERR_BAD_ARG, "rtx_bvh_build: null argument");
+    if (n >= (1u << 26)) return fail(RTX_ERR_BAD_ARG, "rtx_bvh_build: more than 2^26 - 1 surfaces");
+    if (strategy == RTX_BISECT)
+        return fail(RTX_ERR_BAD_ARG, "rtx_bvh_build: LongestAxisBisectSlice depends on the tie order of sort_unstable_by; build it on the host");
+    if (strategy != RTX_MIDPOINT && strategy != RTX_SAH_EQUAL_SIZE && strategy != RTX_SAH_PER_SURFACE)
+        return fail(RTX_ERR_BAD_ARG, "rtx_bvh_build: unknown partition strategy");
+    if (strategy == RTX_SAH_EQUAL_SIZE && buckets < 2u && n >= 2u) return fail(RTX_ERR_BUILD, "No valid splitting plane");
+    for (uint32_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const double lo = leaf_boxes[6ull * i + a], hi = leaf_boxes[6ull * i + 3 + a];
+            if (!std::isfinite(lo) || !std::isfinite(hi) || lo > hi)
+                return fail(RTX_ERR_BAD_ARG, "rtx_bvh_build: box of surface " + std::to_string(i) + " is not finite or has min > max");
+        }
+    if (rtx_device_count() <= 0) return fail(RTX_ERR_NO_DEVICE, "rtx_bvh_build: no HIP device");
+    std::string msg;
+    const int code = build_bvh_device(leaf_boxes, n, strategy, buckets, leaf_order, node_bmin, node_bmax, node_right, node_prim, stats, msg);
+    return code == RTX_OK ? RTX_OK : fail(code, msg);
+}
+
 int rtx_scale(const double* d_accum, uint64_t n, double scale, double* d_out, void* stream) {
     if (n && (!d_accum || !d_out)) return fail(RTX_ERR_BAD_ARG, "rtx_scale: null argument");
     if (n == 0) return RTX_OK;

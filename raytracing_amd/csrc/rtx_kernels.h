@@ -1,5 +1,8 @@
 // rtx_kernels.h -- host-callable launchers of the kernels in rtx_kernels.hip.
 #pragma once
+#include <string>
+
+#include "../../include/rtx.h"
 #include "rtx_device.h"
 
 namespace rtx {
@@ -25,5 +28,9 @@ void launch_rays_to_state(const double* org, const double* dir, uint64_t n, cons
 void launch_user_ids(const uint32_t* rec_user_id, uint32_t n_spheres, uint32_t* ids, uint64_t n, hipStream_t s);
 void launch_selftest_math(int op, const double* a, const double* b, uint64_t n, double* out, hipStream_t s);
 void launch_selftest_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, double* out, hipStream_t s);
+
+// BVH::from_slice on the current device (rtx_build.hip); arguments as rtx_bvh_build, n >= 1.
+int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_t buckets, uint32_t* leaf_order, double* node_bmin,
+                     double* node_bmax, uint32_t* node_right, uint32_t* node_prim, rtx_build_stats* stats, std::string& msg);
 
 }  // namespace rtx

@@ -406,6 +406,47 @@ class BVH {
         return bvh;
     }
 
+    // The same tree with the partitioning done by the device builder
+    // (rtx_bvh_build): the leaf boxes are computed here, the device returns
+    // the leaf order and the node array.  Not for LongestAxisBisectSlice.
+    static BVH from_slice_on_device(std::vector<Surface> surfaces, const PartitionBy& partition_by, rtx_build_stats* stats = nullptr) {
+        BVH bvh;
+        const size_t m = surfaces.size();
+        for (size_t i = 0; i < m; ++i) surfaces[i].user_id = (uint32_t)i;
+        if (m > 0) {
+            std::vector<double> boxes(6 * m);
+            for (size_t i = 0; i < m; ++i) {
+                const AABB b = surfaces[i].bounding_box();
+                for (int a = 0; a < 3; ++a) {
+                    boxes[6 * i + a] = b.min()[a];
+                    boxes[6 * i + 3 + a] = b.max()[a];
+                }
+            }
+            const size_t n = 2 * m - 1;
+            std::vector<uint32_t> leaf_order(m), right(n), prim(n);
+            std::vector<double> bmin(3 * n), bmax(3 * n);
+            int strategy = RTX_BISECT;
+            if (partition_by.kind == PartitionBy::LongestAxisMidpoint) strategy = RTX_MIDPOINT;
+            else if (partition_by.kind == PartitionBy::SurfaceAreaHeuristic)
+                strategy = partition_by.sah.kind == SAHBucketStrategy::EqualSize ? RTX_SAH_EQUAL_SIZE : RTX_SAH_PER_SURFACE;
+            const int rc = rtx_bvh_build(boxes.data(), (uint32_t)m, strategy, partition_by.sah.buckets, leaf_order.data(), bmin.data(),
+                                         bmax.data(), right.data(), prim.data(), stats);
+            if (rc != RTX_OK) throw BuildError(rtx_last_error());
+            bvh.leaves_.reserve(m);
+            for (size_t i = 0; i < m; ++i) bvh.leaves_.push_back(surfaces[leaf_order[i]]);
+            bvh.nodes_.resize(n);
+            for (size_t i = 0; i < n; ++i) {
+                Node& nd = bvh.nodes_[i];
+                nd.leaf = prim[i] != RTX_NONE;
+                nd.right = right[i];
+                nd.leaf_slot = prim[i];
+                nd.box = AABB::from_corners(Vector3{bmin[i], bmin[n + i], bmin[2 * n + i]}, Vector3{bmax[i], bmax[n + i], bmax[2 * n + i]});
+            }
+        }
+        bvh.flatten();
+        return bvh;
+    }
+
     size_t n_nodes() const { return nodes_.size(); }
     size_t n_leaves() const { return leaves_.size(); }
     AABB bounding_box() const { return nodes_.empty() ? AABB::EMPTY() : nodes_[0].box; }   // :176-182
@@ -603,6 +644,7 @@ struct RenderRunner {   // src/runner.rs:8-20
     Camera camera;
     PartitionBy partition_strategy = PartitionBy::surface_area_heuristic(SAHBucketStrategy::per_surface());
     uint64_t seed = 0;   // the reference seeds from the OS; a fixed seed makes a render repeatable
+    bool build_on_device = false;   // BVH::from_slice_on_device instead of the host builder
 
     // src/runner.rs:23-41: build the BVH, render, write the P3 image to
     // `image_out` (the reference prints to stdout) and the three timers to
@@ -610,7 +652,8 @@ struct RenderRunner {   // src/runner.rs:8-20
     std::vector<double> run(std::vector<Surface> surfaces, FILE* image_out = stdout, FILE* log_out = stderr) const {
         using clock = std::chrono::steady_clock;
         const auto start_time = clock::now();
-        const BVH world = BVH::from_slice(std::move(surfaces), partition_strategy);
+        const BVH world = build_on_device ? BVH::from_slice_on_device(std::move(surfaces), partition_strategy)
+                                          : BVH::from_slice(std::move(surfaces), partition_strategy);
         const auto bvh_done = clock::now();
 
         const InitializedCamera cam = camera.initialize();

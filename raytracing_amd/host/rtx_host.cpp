@@ -81,6 +81,23 @@ int rth_bvh_build(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_
     }
 }
 
+int rth_bvh_build_device(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, rth_bvh** out,
+                         rtx_build_stats* stats) {
+    if (!out || (n && !surfaces)) {
+        g_err = "rth_bvh_build_device: null argument";
+        return RTX_ERR_BAD_ARG;
+    }
+    *out = nullptr;
+    try {
+        BVH b = BVH::from_slice_on_device(to_surfaces(surfaces, n), to_partition(strategy, buckets), stats);
+        *out = new rth_bvh{std::move(b)};
+        return RTX_OK;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return RTX_ERR_BUILD;
+    }
+}
+
 void rth_bvh_desc(const rth_bvh* bvh, rtx_scene_desc* out) { *out = bvh->bvh.desc(); }
 
 void rth_bvh_destroy(rth_bvh* bvh) { delete bvh; }
@@ -94,8 +111,8 @@ int rth_camera_initialize(const rtx_camera_config* cfg, rtx_camera* out) {
     return RTX_OK;
 }
 
-int rth_run(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, const rtx_camera_config* cfg,
-            uint64_t seed, const char* ppm_path, double* out_rgb) {
+static int run_impl(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, const rtx_camera_config* cfg,
+                    uint64_t seed, const char* ppm_path, double* out_rgb, bool build_on_device) {
     if (!cfg || (n && !surfaces)) {
         g_err = "rth_run: null argument";
         return RTX_ERR_BAD_ARG;
@@ -106,6 +123,7 @@ int rth_run(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buck
         runner.camera = to_camera(*cfg);
         runner.partition_strategy = to_partition(strategy, buckets);
         runner.seed = seed;
+        runner.build_on_device = build_on_device;
         if (ppm_path) {
             f = std::fopen(ppm_path, "wb");
             if (!f) throw RenderError(std::string("cannot open ") + ppm_path);
@@ -123,6 +141,16 @@ int rth_run(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buck
         g_err = e.what();
         return RTX_ERR_HIP;
     }
+}
+
+int rth_run(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, const rtx_camera_config* cfg,
+            uint64_t seed, const char* ppm_path, double* out_rgb) {
+    return run_impl(surfaces, n, strategy, buckets, cfg, seed, ppm_path, out_rgb, false);
+}
+
+int rth_run_device_build(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, const rtx_camera_config* cfg,
+                         uint64_t seed, const char* ppm_path, double* out_rgb) {
+    return run_impl(surfaces, n, strategy, buckets, cfg, seed, ppm_path, out_rgb, true);
 }
 
 }  // extern "C"
