@@ -145,11 +145,11 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out);
 void rtx_scene_destroy(rtx_scene* scene);
 
 /* BVH::from_slice(surfaces, &partition_by) on the current HIP device
- * (src/bvh/mod.rs:76-131) for RTX_MIDPOINT, RTX_SAH_EQUAL_SIZE(buckets) and
- * RTX_SAH_PER_SURFACE (src/bvh/partition.rs:70-266); the tree is the
- * reference's, node for node.  RTX_BISECT is refused: it rests on
- * sort_unstable_by (partition.rs:58-68), whose order of equal keys the
- * reference leaves open.
+ * (src/bvh/mod.rs:76-131) for every strategy of enum rtx_partition
+ * (src/bvh/partition.rs:58-266); the tree is the reference's, node for node.
+ * RTX_BISECT rests on sort_unstable_by (partition.rs:58-68), whose order of
+ * equal keys the reference leaves open: here, as in rth_bvh_build, equal keys
+ * keep their order.
  * leaf_boxes: host, [n][6] = Surface::bounding_box of every surface
  * (min x,y,z, max x,y,z).  Outputs, host: leaf_order[n] = index of the
  * surface that is the i-th leaf in pre-order (the order `surfaces` is left

@@ -62,8 +62,8 @@ const char* rth_last_error(void);
  * (src/bvh/partition.rs:219), a negative sphere radius
  * (src/geometry.rs:56-62), a partition with an empty side. */
 int rth_bvh_build(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, rth_bvh** out);
-/* The same tree with the partitioning done on the current HIP device
- * (rtx_bvh_build); the surfaces' boxes and the flattened tables are made on
+/* The same tree, for every strategy, with the partitioning done on the
+ * current HIP device (rtx_bvh_build); the surfaces' boxes and the flattened tables are made on
  * the host.  stats may be NULL. */
 int rth_bvh_build_device(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, rth_bvh** out,
                          rtx_build_stats* stats);

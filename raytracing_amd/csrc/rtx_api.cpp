@@ -756,9 +756,7 @@ int rtx_bvh_build(const double* leaf_boxes, uint32_t n, int strategy, uint32_t b
     if (!leaf_boxes || !leaf_order || !node_bmin || !node_bmax || !node_right || !node_prim)
         return fail(RTX_ERR_BAD_ARG, "rtx_bvh_build: null argument");
     if (n >= (1u << 26)) return fail(RTX_ERR_BAD_ARG, "rtx_bvh_build: more than 2^26 - 1 surfaces");
-    if (strategy == RTX_BISECT)
-        return fail(RTX_ERR_BAD_ARG, "rtx_bvh_build: LongestAxisBisectSlice depends on the tie order of sort_unstable_by; build it on the host");
-    if (strategy != RTX_MIDPOINT && strategy != RTX_SAH_EQUAL_SIZE && strategy != RTX_SAH_PER_SURFACE)
+    if (strategy != RTX_BISECT && strategy != RTX_MIDPOINT && strategy != RTX_SAH_EQUAL_SIZE && strategy != RTX_SAH_PER_SURFACE)
         return fail(RTX_ERR_BAD_ARG, "rtx_bvh_build: unknown partition strategy");
     if (strategy == RTX_SAH_EQUAL_SIZE && buckets < 2u && n >= 2u) return fail(RTX_ERR_BUILD, "No valid splitting plane");
     for (uint32_t i = 0; i < n; ++i)

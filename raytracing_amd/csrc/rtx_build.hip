@@ -1,6 +1,5 @@
 // rtx_build.hip -- `BVH::from_slice` (src/bvh/mod.rs:76-131) on the device,
-// for PartitionBy::LongestAxisMidpoint and both SurfaceAreaHeuristic bucket
-// strategies (src/bvh/partition.rs:70-266).  Citations are into the reference.
+// for every PartitionBy strategy (src/bvh/partition.rs:58-266).  Citations are into the reference.
 //
 // The reference recurses depth first and, at every node, sorts the node's
 // surfaces three times (splits_cache, partition.rs:119-171).  Here the tree is
@@ -211,7 +210,9 @@ struct BoxScan {
         if (s == NONE) return r;   // a finished leaf: a segment of its own, value never read
         const bool edge = back ? pos == B.n - 1u : pos == 0u;
         r.f = (edge || B.seg_at[back ? pos + 1u : pos - 1u] != s) ? 1u : 0u;
-        const double* b = B.box + 6ull * B.sid[cur][axis][pos];
+        // bisection keeps no sorted lists: the fold over the surface order gives the same box
+        const uint32_t* list = B.strategy == RTX_BISECT ? B.order[cur] : B.sid[cur][axis];
+        const double* b = B.box + 6ull * list[pos];
 #pragma unroll
         for (int k = 0; k < 6; ++k) r.v[k] = b[k];
         return r;
@@ -396,7 +397,10 @@ __global__ void __launch_bounds__(BLOCK) k_decide(DBuild B, uint32_t cur, uint32
     B.seg_nleft[s] = m;
     B.seg_child[0][s] = NONE;
     B.seg_child[1][s] = NONE;
-    if (B.strategy == RTX_MIDPOINT) {
+    if (B.strategy == RTX_BISECT) {   // longest_axis_bisect_slice, partition.rs:58-68: sort on the axis, split in the middle
+        axis = longest_axis(bb);
+        n_left = m / 2u;
+    } else if (B.strategy == RTX_MIDPOINT) {
         axis = longest_axis(bb);
         at = bb[axis] + (bb[3 + axis] - bb[axis]) * 0.5;   // AABB::centroid, src/aabb.rs:29-31
         strict = 1;
@@ -531,6 +535,33 @@ __global__ void __launch_bounds__(BLOCK) k_reorder(DBuild B, uint32_t cur) {
     const uint32_t id = B.order[cur][from];
     B.order[nxt][pos] = id;
     B.pos_of[id] = pos;
+}
+
+// LongestAxisBisectSlice: every segment is sorted by the lower box corner on
+// its longest axis (partition.rs:58-68), ties keeping their current order.
+// Two stable radix sorts over all positions do that for every segment at
+// once: by the coordinate, then by the first position of the element's
+// segment (a finished leaf counts as a segment of its own), which puts every
+// segment back onto its own positions.
+__global__ void __launch_bounds__(BLOCK) k_bisect_coordinate_keys(DBuild B, uint32_t cur, unsigned long long* keys) {
+    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= B.n) return;
+    const uint32_t s = B.seg_at[pos];
+    keys[pos] = s == NONE ? 0ull : ordered_key(B.box[6ull * B.order[cur][pos] + B.seg_axis[s]]);
+}
+__global__ void __launch_bounds__(BLOCK) k_bisect_segment_keys(DBuild B, uint32_t cur, const uint32_t* by_coordinate, uint32_t* keys) {
+    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= B.n) return;
+    const uint32_t pos = B.pos_of[by_coordinate[j]];
+    const uint32_t s = B.seg_at[pos];
+    keys[j] = s == NONE ? pos : B.seg_a[cur][s];
+}
+__global__ void __launch_bounds__(BLOCK) k_bisect_finish(DBuild B, uint32_t cur) {
+    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= B.n) return;
+    B.pos_of[B.order[cur ^ 1u][pos]] = pos;
+    const uint32_t s = B.seg_at[pos];
+    if (s != NONE) B.seg_at[pos] = B.seg_child[pos < B.seg_a[cur][s] + (B.seg_nleft[s] & 0x7FFFFFFFu) ? 0 : 1][s];
 }
 
 __global__ void __launch_bounds__(BLOCK) k_init(DBuild B, unsigned long long* sort_keys, uint32_t* sort_vals) {
@@ -687,6 +718,12 @@ int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_
     B.n_nodes = 2u * n - 1u;
     BUILD_TRY((hipError_t)rocprim::radix_sort_pairs(nullptr, sort_tmp_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                                    (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 64, st));
+    {
+        size_t bytes32 = 0;
+        BUILD_TRY((hipError_t)rocprim::radix_sort_pairs(nullptr, bytes32, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                                       (uint32_t*)nullptr, n, 0, 32, st));
+        if (bytes32 > sort_tmp_bytes) sort_tmp_bytes = bytes32;
+    }
     carve(ar, plan, n, sort_tmp_bytes);   // sizes only
     ar.size = ar.used + 256u;
     BUILD_TRY(hipMalloc((void**)&ar.base, ar.size));
@@ -697,17 +734,19 @@ int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_
     BUILD_TRY(hipMemcpyAsync(const_cast<double*>(B.box), leaf_boxes, 6ull * n * sizeof(double), hipMemcpyHostToDevice, st));
 
     hipLaunchKernelGGL(k_init, dim3(grid), dim3(BLOCK), 0, st, B, plan.sort_keys_in, plan.sort_vals);
-    for (int ax = 0; ax < 3; ++ax)
-        BUILD_TRY((hipError_t)rocprim::radix_sort_pairs(plan.sort_tmp, plan.sort_tmp_bytes, plan.sort_keys_in + (size_t)ax * n, plan.sort_keys_out,
-                                                       plan.sort_vals, B.sid[0][ax], n, 0, 64, st));
-    hipLaunchKernelGGL(k_sorted_keys, dim3(grid, 3), dim3(BLOCK), 0, st, B);
+    if (strategy != RTX_BISECT) {
+        for (int ax = 0; ax < 3; ++ax)
+            BUILD_TRY((hipError_t)rocprim::radix_sort_pairs(plan.sort_tmp, plan.sort_tmp_bytes, plan.sort_keys_in + (size_t)ax * n,
+                                                           plan.sort_keys_out, plan.sort_vals, B.sid[0][ax], n, 0, 64, st));
+        hipLaunchKernelGGL(k_sorted_keys, dim3(grid, 3), dim3(BLOCK), 0, st, B);
+    }
     BUILD_TRY(hipEventRecord(ev[1], st));
 
     while (n_seg > 0u) {
         const uint32_t seg_grid = (n_seg + BLOCK - 1u) / BLOCK;
         BoxScan box_scan{B, cur};
         // a midpoint split needs the segment boxes only (x order, forward); the SAH needs all six folds
-        run_scan(box_scan, n, strategy == RTX_MIDPOINT ? 1u : 6u, plan.box_totals, st);
+        run_scan(box_scan, n, strategy == RTX_MIDPOINT || strategy == RTX_BISECT ? 1u : 6u, plan.box_totals, st);
         hipLaunchKernelGGL(k_reset_best, dim3(seg_grid), dim3(BLOCK), 0, st, B, n_seg);
         if (strategy == RTX_SAH_PER_SURFACE) {
             hipLaunchKernelGGL(k_candidates_per_surface, dim3(grid, 3), dim3(BLOCK), 0, st, B, cur);
@@ -719,10 +758,20 @@ int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_
             hipLaunchKernelGGL(k_candidates_equal_size<1>, dim3(cand_grid), dim3(BLOCK), 0, st, B, cur, n_seg);
         }
         hipLaunchKernelGGL(k_decide, dim3(seg_grid), dim3(BLOCK), 0, st, B, cur, n_seg);
-        hipLaunchKernelGGL(k_flags, dim3(grid), dim3(BLOCK), 0, st, B, cur);
-        run_scan(FlagScan{B}, n, 1u, plan.flag_totals, st);
-        hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(BLOCK), 0, st, B, cur);
-        hipLaunchKernelGGL(k_reorder, dim3(grid), dim3(BLOCK), 0, st, B, cur);
+        if (strategy == RTX_BISECT) {
+            hipLaunchKernelGGL(k_bisect_coordinate_keys, dim3(grid), dim3(BLOCK), 0, st, B, cur, plan.sort_keys_in);
+            BUILD_TRY((hipError_t)rocprim::radix_sort_pairs(plan.sort_tmp, plan.sort_tmp_bytes, plan.sort_keys_in, plan.sort_keys_out, B.order[cur],
+                                                           plan.sort_vals, n, 0, 64, st));
+            hipLaunchKernelGGL(k_bisect_segment_keys, dim3(grid), dim3(BLOCK), 0, st, B, cur, plan.sort_vals, B.F);
+            BUILD_TRY((hipError_t)rocprim::radix_sort_pairs(plan.sort_tmp, plan.sort_tmp_bytes, B.F, B.G, plan.sort_vals, B.order[cur ^ 1u], n, 0,
+                                                           32, st));
+            hipLaunchKernelGGL(k_bisect_finish, dim3(grid), dim3(BLOCK), 0, st, B, cur);
+        } else {
+            hipLaunchKernelGGL(k_flags, dim3(grid), dim3(BLOCK), 0, st, B, cur);
+            run_scan(FlagScan{B}, n, 1u, plan.flag_totals, st);
+            hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(BLOCK), 0, st, B, cur);
+            hipLaunchKernelGGL(k_reorder, dim3(grid), dim3(BLOCK), 0, st, B, cur);
+        }
         BUILD_TRY(hipMemcpyAsync(host_ctl, B.ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
         BUILD_TRY(hipStreamSynchronize(st));
         if (host_ctl[1] != 0u) {

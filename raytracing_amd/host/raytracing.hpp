@@ -408,7 +408,7 @@ class BVH {
 
     // The same tree with the partitioning done by the device builder
     // (rtx_bvh_build): the leaf boxes are computed here, the device returns
-    // the leaf order and the node array.  Not for LongestAxisBisectSlice.
+    // the leaf order and the node array.
     static BVH from_slice_on_device(std::vector<Surface> surfaces, const PartitionBy& partition_by, rtx_build_stats* stats = nullptr) {
         BVH bvh;
         const size_t m = surfaces.size();

@@ -54,8 +54,8 @@ def compare(rt, surfaces, strategy, buckets=0):
     return bvh
 
 
-STRATEGIES = [(1, 0), (2, 8), (2, 16), (3, 0)]
-STRATEGY_IDS = ["midpoint", "sah_equal_size_8", "sah_equal_size_16", "sah_per_surface"]
+STRATEGIES = [(0, 0), (1, 0), (2, 8), (2, 16), (3, 0)]
+STRATEGY_IDS = ["bisect", "midpoint", "sah_equal_size_8", "sah_equal_size_16", "sah_per_surface"]
 
 
 def reference_cases():
@@ -79,7 +79,7 @@ def test_reference_unit_test_scenes(rt, oracle, case, strategy, buckets):
 
 
 def test_reference_expected_trees(rt, oracle):
-    """The node arrays the reference's tests spell out (src/bvh/mod.rs:289-344, 386-479)."""
+    """The node arrays the reference's five tests spell out (src/bvh/mod.rs:191-479)."""
     from test_builder_reference_cases import check, merge, demo_scene
 
     def check_device(surfaces, strategy, expected, buckets=0):
@@ -96,6 +96,10 @@ def test_reference_expected_trees(rt, oracle):
 
     tl, bl, tr, br = sph(-2, 1, 0, 0.5), sph(-2, -1, 0, 0.5), sph(2, 1, 0, 0.5), sph(2, -1, 0, 0.5)
     bb = [oracle.surface_bbox(s) for s in (tl, bl, tr, br)]
+    balanced = [("I", 4, merge(*bb)), ("I", 3, merge(bb[1], bb[0])), ("L", 1), ("L", 0), ("I", 6, merge(bb[3], bb[2])), ("L", 3), ("L", 2)]
+    check_device([tl, bl, tr, br], 0, balanced)                                               # src/bvh/mod.rs:191-246
+    b3 = [oracle.surface_bbox(s) for s in (tl, bl, br)]
+    check_device([tl, bl, br], 0, [("I", 2, merge(*b3)), ("L", 0), ("I", 4, merge(b3[1], b3[2])), ("L", 1), ("L", 2)])   # :248-287
     check_device([tl, bl, tr, br], 1, [("I", 4, merge(*bb)), ("I", 3, merge(bb[1], bb[0])), ("L", 1), ("L", 0),
                                        ("I", 6, merge(bb[3], bb[2])), ("L", 3), ("L", 2)])
     scene = list(demo_scene())
@@ -148,9 +152,6 @@ def test_failures_match_the_host_builder(rt):
         compare(rt, same, strategy, buckets)   # host fails -> device must fail with the same message
     with pytest.raises(rt.RtxError):
         rt.HostBVH(same, 3, device=True)
-    with pytest.raises(rt.RtxError) as e:
-        rt.HostBVH(lattice(2, 2, 2), 0, device=True)
-    assert "LongestAxisBisectSlice" in str(e.value)
     with pytest.raises(rt.RtxError):
         rt.HostBVH(lattice(2, 2, 2), 2, 1, device=True)   # one bucket: no candidate plane
 
