@@ -55,12 +55,13 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
 };
 
-uint32_t env_u32(const char* name, uint32_t dflt) {
+// Sizes and counts: 0 is not a valid value and yields the default; switches pass zero_ok.
+uint32_t env_u32(const char* name, uint32_t dflt, bool zero_ok = false) {
     const char* v = std::getenv(name);
     if (!v || !*v) return dflt;
     char* end = nullptr;
     unsigned long long x = std::strtoull(v, &end, 10);
-    if (end == v || x == 0 || x > 0xFFFFFFFFull) return dflt;
+    if (end == v || (x == 0 && !zero_ok) || x > 0xFFFFFFFFull) return dflt;
     return (uint32_t)x;
 }
 
@@ -512,7 +513,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
 
     // Default path: the whole sample loop as ONE launch of persistent waves on the caller's stream.  It needs the
     // single-precision box tier; calls that ask for another tier, or scenes outside its range, take the round loop below.
-    if (sc->f32_ok && !(flags & (RTX_FLAG_EXACT_DIVIDE | RTX_FLAG_F64_FILTER | RTX_FLAG_TIME_KERNELS)) && env_u32("RTX_PERSISTENT", 1) == 1u) {
+    if (sc->f32_ok && !(flags & (RTX_FLAG_EXACT_DIVIDE | RTX_FLAG_F64_FILTER | RTX_FLAG_TIME_KERNELS)) && env_u32("RTX_PERSISTENT", 1, true) != 0u) {
         PathPool* pp = sc->lane(0);
         const uint32_t mode = lds_mode_for(sc, flags);
         const uint32_t waves = sc->n_cus * persistent_waves_per_cu(sc->d, mode);   // exactly what is resident at once
