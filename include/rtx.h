@@ -193,12 +193,28 @@ int rtx_scale(const double* d_accum, uint64_t n_values, double scale, double* d_
 /* ppm_pixel (src/camera.rs:248-266) on the device: gamma, clamp, 8-bit. */
 int rtx_quantize(const double* d_rgb, uint64_t n_values, uint8_t* d_out, void* stream);
 
+/* The text InitializedCamera::render prints (src/camera.rs:129-131,155-161),
+ * byte for byte: "P3\n{W} {H}\n255\n", then "{r} {g} {b}\n" per pixel with
+ * ppm_pixel's values (src/camera.rs:248-266), formatted on the device.
+ * d_rgb: device, [H][W][3] f64 linear RGB.  out_text: host, `capacity` bytes;
+ * rtx_ppm_text_bound(W, H) bytes are always enough.  *out_len = bytes written
+ * (no terminating NUL).  At most 2^28 pixels. */
+uint64_t rtx_ppm_text_bound(uint32_t width, uint32_t height);
+int rtx_ppm_text(const double* d_rgb, uint32_t width, uint32_t height, char* out_text, uint64_t capacity,
+                 uint64_t* out_len, void* stream);
+
 /* Whole render on the current device with host output: out_rgb is host
  * memory, [H][W][3] f64 linear RGB already multiplied by 1/spp.  Replaces
  * `camera.initialize().render(&world)` (src/runner.rs:31) minus the PPM
  * text output. */
 int rtx_render(rtx_scene* scene, const rtx_camera* cam, uint64_t seed, uint32_t flags,
                double* out_rgb, rtx_stats* stats);
+
+/* The whole of `camera.initialize().render(&world)` (src/camera.rs:128-162,
+ * src/runner.rs:31): rtx_render plus the P3 text of rtx_ppm_text.  out_rgb
+ * (host, [H][W][3]) or out_text (host, `capacity` bytes) may be NULL. */
+int rtx_render_ppm(rtx_scene* scene, const rtx_camera* cam, uint64_t seed, uint32_t flags, double* out_rgb,
+                   char* out_text, uint64_t capacity, uint64_t* out_len, rtx_stats* stats);
 
 /* Device arithmetic self-test hooks used by the parity tests:
  * op 0: out[i] = a[i] / b[i]; op 1: out[i] = sqrt(a[i]);

@@ -106,7 +106,7 @@ class BuildStats(C.Structure):  # rtx_build_stats
 ABI_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_trace_closest",
     "rtx_primary_rays", "rtx_render_accumulate", "rtx_scale", "rtx_quantize", "rtx_render", "rtx_selftest_math",
-    "rtx_selftest_rng", "rtx_bvh_build",
+    "rtx_selftest_rng", "rtx_bvh_build", "rtx_ppm_text_bound", "rtx_ppm_text", "rtx_render_ppm",
     "rth_last_error", "rth_bvh_build", "rth_bvh_build_device", "rth_run_device_build", "rth_bvh_desc", "rth_bvh_destroy", "rth_camera_initialize", "rth_run",
 ]
 
@@ -128,6 +128,10 @@ _lib.rth_bvh_build.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, _p(C
 _lib.rth_bvh_build_device.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, _p(C.c_void_p), _p(BuildStats)]
 _lib.rtx_bvh_build.argtypes = [_dp, C.c_uint32, C.c_int, C.c_uint32, _u32p, _dp, _dp, _u32p, _u32p, _p(BuildStats)]
 _lib.rth_run_device_build.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, _p(CameraConfig), C.c_uint64, C.c_char_p, _dp]
+_lib.rtx_ppm_text_bound.argtypes = [C.c_uint32, C.c_uint32]
+_lib.rtx_ppm_text_bound.restype = C.c_uint64
+_lib.rtx_ppm_text.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, _p(C.c_uint64), C.c_void_p]
+_lib.rtx_render_ppm.argtypes = [C.c_void_p, _p(Camera), C.c_uint64, C.c_uint32, _dp, C.c_char_p, C.c_uint64, _p(C.c_uint64), _p(Stats)]
 _lib.rth_bvh_desc.argtypes = [C.c_void_p, _p(SceneDesc)]
 _lib.rth_bvh_desc.restype = None
 _lib.rth_bvh_destroy.argtypes = [C.c_void_p]
@@ -177,6 +181,15 @@ def camera_initialize(cam):
     out = Camera()
     _check(_lib.rth_camera_initialize(C.byref(cfg), C.byref(out)), host=True)
     return out
+
+
+def ppm_text(d_rgb_ptr, width, height, stream=None):
+    """``rtx_ppm_text``: the P3 text (bytes) of a device-resident [H, W, 3] f64 linear image."""
+    cap = int(_lib.rtx_ppm_text_bound(width, height))
+    buf = C.create_string_buffer(cap)
+    n = C.c_uint64(0)
+    _check(_lib.rtx_ppm_text(d_rgb_ptr, width, height, buf, cap, C.byref(n), stream))
+    return buf.raw[: n.value]
 
 
 def bvh_build_device(leaf_boxes, strategy=SAH_PER_SURFACE, buckets=0):

@@ -750,6 +750,18 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     return status;
 }
 
+uint64_t rtx_ppm_text_bound(uint32_t width, uint32_t height) { return 48ull + 12ull * width * height; }
+
+int rtx_ppm_text(const double* d_rgb, uint32_t width, uint32_t height, char* out_text, uint64_t capacity, uint64_t* out_len, void* stream) {
+    if (!d_rgb || !out_text || !out_len) return fail(RTX_ERR_BAD_ARG, "rtx_ppm_text: null argument");
+    if (width == 0 || height == 0) return fail(RTX_ERR_BAD_ARG, "rtx_ppm_text: empty image");
+    if ((uint64_t)width * height > (1ull << 28)) return fail(RTX_ERR_BAD_ARG, "rtx_ppm_text: more than 2^28 pixels");
+    if (rtx_device_count() <= 0) return fail(RTX_ERR_NO_DEVICE, "rtx_ppm_text: no HIP device");
+    std::string msg;
+    const int code = ppm_text_device(d_rgb, width, height, out_text, capacity, out_len, (hipStream_t)stream, msg);
+    return code == RTX_OK ? RTX_OK : fail(code, msg);
+}
+
 int rtx_bvh_build(const double* leaf_boxes, uint32_t n, int strategy, uint32_t buckets, uint32_t* leaf_order, double* node_bmin,
                   double* node_bmax, uint32_t* node_right, uint32_t* node_prim, rtx_build_stats* stats) {
     if (stats) std::memset(stats, 0, sizeof *stats);
@@ -788,9 +800,10 @@ int rtx_quantize(const double* d_rgb, uint64_t n, uint8_t* d_out, void* stream) 
     return RTX_OK;
 }
 
-int rtx_render(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, uint32_t flags, double* out_rgb, rtx_stats* stats) {
-    if (!sc || !out_rgb) return fail(RTX_ERR_BAD_ARG, "rtx_render: null argument");
-    int rc = check_camera(cam, "rtx_render");
+int rtx_render_ppm(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, uint32_t flags, double* out_rgb, char* out_text,
+                   uint64_t capacity, uint64_t* out_len, rtx_stats* stats) {
+    if (!sc || (!out_rgb && !out_text) || (out_text && !out_len)) return fail(RTX_ERR_BAD_ARG, "rtx_render_ppm: null argument");
+    int rc = check_camera(cam, "rtx_render_ppm");
     if (rc != RTX_OK) return rc;
     HIP_TRY(hipSetDevice(sc->device));
     const uint64_t nval = 3ull * cam->image_width * cam->image_height;
@@ -801,8 +814,17 @@ int rtx_render(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, uint32_t fla
     if (rc != RTX_OK) return rc;
     rc = rtx_scale(acc.p, nval, cam->pixel_samples_scale, acc.p, nullptr);
     if (rc != RTX_OK) return rc;
-    HIP_TRY(hipMemcpy(out_rgb, acc.p, nval * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_text) {
+        rc = rtx_ppm_text(acc.p, cam->image_width, cam->image_height, out_text, capacity, out_len, nullptr);
+        if (rc != RTX_OK) return rc;
+    }
+    if (out_rgb) HIP_TRY(hipMemcpy(out_rgb, acc.p, nval * sizeof(double), hipMemcpyDeviceToHost));
     return RTX_OK;
+}
+
+int rtx_render(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, uint32_t flags, double* out_rgb, rtx_stats* stats) {
+    if (!out_rgb) return fail(RTX_ERR_BAD_ARG, "rtx_render: null argument");
+    return rtx_render_ppm(sc, cam, seed, flags, out_rgb, nullptr, 0, nullptr, stats);
 }
 
 int rtx_selftest_math(int op, const double* a, const double* b, uint64_t n, double* out) {

@@ -31,14 +31,14 @@
 
 #include "../../include/rtx.h"
 #include "rtx_kernels.h"
+#include "rtx_scan.h"
 
 namespace rtx {
 namespace build {
 
-constexpr uint32_t BLOCK = 256;
-constexpr uint32_t WAVES = BLOCK / 64;
-constexpr uint32_t ITEMS = 4;
-constexpr uint32_t TILE = BLOCK * ITEMS;
+using scan::BLOCK;
+using scan::TILE;
+using scan::run_scan;
 constexpr unsigned long long NO_COST = ~0ull;
 
 enum : uint32_t { ERR_NO_PLANE = 1, ERR_EMPTY_SIDE = 2, ERR_INTERNAL = 3 };
@@ -76,7 +76,7 @@ struct DBuild {
     double* node_bmax;
 };
 
-__device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
+using scan::lane;
 
 // f64::total_cmp as an unsigned key
 __device__ __forceinline__ unsigned long long ordered_key(double x) {
@@ -96,95 +96,6 @@ __device__ __forceinline__ SBox shfl_up_t(const SBox& x, uint32_t d) {
     for (int k = 0; k < 6; ++k) r.v[k] = __shfl_up(x.v[k], d);
     r.f = __shfl_up(x.f, d);
     return r;
-}
-__device__ __forceinline__ uint4 shfl_up_t(const uint4& x, uint32_t d) {
-    return make_uint4(__shfl_up(x.x, d), __shfl_up(x.y, d), __shfl_up(x.z, d), __shfl_up(x.w, d));
-}
-
-// Inclusive scan of BLOCK*N values held N per thread, seeded with `carry`.
-// On return x[] holds the inclusive results, `total` = carry combined with the whole tile.
-template <uint32_t N, class Op, class T>
-__device__ __forceinline__ void block_scan(const Op& op, T (&x)[N], const T& carry, T* lds, T& total) {
-#pragma unroll
-    for (uint32_t i = 1; i < N; ++i) x[i] = op.combine(x[i - 1], x[i]);
-    T inc = x[N - 1];
-#pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const T up = shfl_up_t(inc, d);
-        if (lane() >= d) inc = op.combine(up, inc);
-    }
-    const uint32_t wave = threadIdx.x >> 6;
-    if (lane() == 63) lds[wave] = inc;
-    __syncthreads();
-    T prefix = carry;
-    total = carry;
-#pragma unroll
-    for (uint32_t w = 0; w < WAVES; ++w) {
-        if (w < wave) prefix = op.combine(prefix, lds[w]);
-        total = op.combine(total, lds[w]);
-    }
-    const T before = shfl_up_t(inc, 1);
-    if (lane() > 0) prefix = op.combine(prefix, before);
-#pragma unroll
-    for (uint32_t i = 0; i < N; ++i) x[i] = op.combine(prefix, x[i]);
-    __syncthreads();
-}
-
-// Three launches: tile totals, exclusive scan of the totals (one block per
-// row y), tiles again with their carry.  Op: T, identity(), load(i, y),
-// combine(a, b), store(i, y, inclusive).
-template <class Op>
-__global__ void __launch_bounds__(BLOCK) k_scan_totals(Op op, uint32_t n, typename Op::T* totals) {
-    using T = typename Op::T;
-    __shared__ T lds[WAVES];
-    T x[ITEMS];
-    const uint32_t base = blockIdx.x * TILE + threadIdx.x * ITEMS;
-#pragma unroll
-    for (uint32_t i = 0; i < ITEMS; ++i) x[i] = base + i < n ? op.load(base + i, blockIdx.y) : op.identity();
-    T total;
-    block_scan<ITEMS>(op, x, op.identity(), lds, total);
-    if (threadIdx.x == 0) totals[blockIdx.y * gridDim.x + blockIdx.x] = total;
-}
-
-template <class Op>
-__global__ void __launch_bounds__(BLOCK) k_scan_spine(Op op, uint32_t n_tiles, typename Op::T* totals) {
-    using T = typename Op::T;
-    __shared__ T lds[WAVES];
-    T* row = totals + (size_t)blockIdx.x * n_tiles;
-    T carry = op.identity();
-    for (uint32_t first = 0; first < n_tiles; first += BLOCK) {
-        const uint32_t i = first + threadIdx.x;
-        T x[1];
-        x[0] = i < n_tiles ? row[i] : op.identity();
-        const T own = x[0];
-        T total;
-        block_scan<1>(op, x, carry, lds, total);
-        // exclusive: what precedes tile i
-        const T before = shfl_up_t(x[0], 1);
-        __shared__ T edge[WAVES];
-        if (lane() == 63) edge[threadIdx.x >> 6] = x[0];
-        __syncthreads();
-        T excl = lane() > 0 ? before : ((threadIdx.x >> 6) > 0 ? edge[(threadIdx.x >> 6) - 1] : carry);
-        (void)own;
-        if (i < n_tiles) row[i] = excl;
-        carry = total;
-        __syncthreads();
-    }
-}
-
-template <class Op>
-__global__ void __launch_bounds__(BLOCK) k_scan_apply(Op op, uint32_t n, const typename Op::T* totals) {
-    using T = typename Op::T;
-    __shared__ T lds[WAVES];
-    T x[ITEMS];
-    const uint32_t base = blockIdx.x * TILE + threadIdx.x * ITEMS;
-#pragma unroll
-    for (uint32_t i = 0; i < ITEMS; ++i) x[i] = base + i < n ? op.load(base + i, blockIdx.y) : op.identity();
-    T total;
-    block_scan<ITEMS>(op, x, totals[blockIdx.y * gridDim.x + blockIdx.x], lds, total);
-#pragma unroll
-    for (uint32_t i = 0; i < ITEMS; ++i)
-        if (base + i < n) op.store(base + i, blockIdx.y, x[i]);
 }
 
 // Row y = axis + 3*direction.  Direction 0 folds the boxes of a segment's
@@ -675,14 +586,6 @@ void carve(Arena& ar, Plan& p, uint32_t n, size_t sort_tmp_bytes) {
     p.flag_totals = ar.take<uint4>(n_tiles);
     p.sort_tmp = ar.take<char>(sort_tmp_bytes);
     p.sort_tmp_bytes = sort_tmp_bytes;
-}
-
-template <class Op>
-void run_scan(const Op& op, uint32_t n, uint32_t rows, typename Op::T* totals, hipStream_t st) {
-    const uint32_t n_tiles = (n + TILE - 1u) / TILE;
-    hipLaunchKernelGGL(k_scan_totals<Op>, dim3(n_tiles, rows), dim3(BLOCK), 0, st, op, n, totals);
-    hipLaunchKernelGGL(k_scan_spine<Op>, dim3(rows), dim3(BLOCK), 0, st, op, n_tiles, totals);
-    hipLaunchKernelGGL(k_scan_apply<Op>, dim3(n_tiles, rows), dim3(BLOCK), 0, st, op, n, totals);
 }
 
 #define BUILD_TRY(expr)                                                                   \

@@ -33,4 +33,8 @@ void launch_selftest_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_
 int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_t buckets, uint32_t* leaf_order, double* node_bmin,
                      double* node_bmax, uint32_t* node_right, uint32_t* node_prim, rtx_build_stats* stats, std::string& msg);
 
+// The P3 text of an image on the current device (rtx_output.hip); arguments as rtx_ppm_text.
+int ppm_text_device(const double* d_rgb, uint32_t width, uint32_t height, char* out, uint64_t capacity, uint64_t* out_len, hipStream_t st,
+                    std::string& msg);
+
 }  // namespace rtx

@@ -661,22 +661,13 @@ struct RenderRunner {   // src/runner.rs:8-20
         const rtx_scene_desc desc = world.desc();
         if (rtx_scene_create(&desc, &scene) != RTX_OK) throw RenderError(rtx_last_error());
         std::vector<double> image(3 * (size_t)cam.image_width * cam.image_height);
+        std::vector<char> text(image_out ? rtx_ppm_text_bound(cam.image_width, cam.image_height) : 0);   // src/camera.rs:129-131,155-161
+        uint64_t text_len = 0;
         rtx_stats stats;
-        const int rc = rtx_render(scene, &cam, seed, 0, image.data(), &stats);
+        const int rc = rtx_render_ppm(scene, &cam, seed, 0, image.data(), image_out ? text.data() : nullptr, text.size(), &text_len, &stats);
         rtx_scene_destroy(scene);
         if (rc != RTX_OK) throw RenderError(rtx_last_error());
-
-        if (image_out) {   // src/camera.rs:129-131,155-161
-            std::string body;
-            body.reserve(image.size() * 4 + 32);
-            body += "P3\n" + std::to_string(cam.image_width) + " " + std::to_string(cam.image_height) + "\n255\n";
-            for (size_t p = 0; p < (size_t)cam.image_width * cam.image_height; ++p) {
-                uint8_t px[3];
-                ppm_pixel(&image[3 * p], px);
-                body += std::to_string(px[0]) + " " + std::to_string(px[1]) + " " + std::to_string(px[2]) + "\n";
-            }
-            std::fwrite(body.data(), 1, body.size(), image_out);
-        }
+        if (image_out) std::fwrite(text.data(), 1, text_len, image_out);
         const auto done = clock::now();
         if (log_out) {
             auto secs = [](clock::duration d) { return std::chrono::duration<double>(d).count(); };

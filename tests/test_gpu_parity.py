@@ -363,3 +363,40 @@ def test_quantize_matches_oracle(rt, oracle):
     rt.scale(d.data_ptr(), d.numel(), 0.002, out.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(bits(out.cpu().numpy()), bits(x * 0.002))
+
+
+def expected_ppm(oracle, img):
+    """The reference's output (src/camera.rs:129-131,155-161) from the oracle's ppm_pixel values."""
+    h, w, _ = img.shape
+    q = oracle.ppm_quantize(img.reshape(-1, 3))
+    lines = "".join(f"{r} {g} {b}\n" for r, g, b in q.tolist())
+    return f"P3\n{w} {h}\n255\n{lines}".encode()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 17), (64, 16), (135, 240), (1080, 1920)])
+def test_ppm_text_is_the_references_output(rt, oracle, shape):
+    import torch
+
+    rng = np.random.default_rng(shape[0] * 7919 + shape[1])
+    img = rng.uniform(-0.2, 1.3, shape + (3,)) ** 2   # values on both sides of every digit-count boundary and of the clamp
+    special = [np.nan, np.inf, -np.inf, 0.0, 1e-300, 0.998001, 0.998002]
+    k = min(img.size, len(special))
+    img.reshape(-1)[:k] = special[:k]
+    d = torch.from_numpy(img).cuda()
+    got = rt.ppm_text(d.data_ptr(), shape[1], shape[0])
+    assert got == expected_ppm(oracle, img)
+
+
+def test_runner_writes_the_references_ppm(rt, oracle, tmp_path):
+    """RenderRunner::run (rth_run): the file is the P3 text of the image it returns."""
+    import ctypes as C
+
+    surfaces, cam = S.EXAMPLES["quads"]()
+    cfg = rt.camera_config(dict(cam, samples_per_pixel=4, image_width=160))
+    icam = rt.camera_initialize(cfg)
+    img = np.zeros((icam.image_height, icam.image_width, 3))
+    path = tmp_path / "out.ppm"
+    rc = rt._lib.rth_run(surfaces.ctypes.data_as(C.c_void_p), len(surfaces), 3, 0, C.byref(cfg), 5, str(path).encode(),
+                         img.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0, rt._lib.rth_last_error()
+    assert path.read_bytes() == expected_ppm(oracle, img)
