@@ -136,8 +136,6 @@ struct rtx_scene {
     DevBuf<DNode> nodes;
     DevBuf<DSphere> spheres;
     DevBuf<DPlanar> planars;
-    DevBuf<DPrimInfo> prims;
-    DevBuf<DMaterial> materials;
     DevBuf<DNode32> nodes32;
     DevBuf<DBox64> boxes64;
     DevBuf<uint32_t> rec_user_id;
@@ -307,8 +305,6 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     UP(nodes, nodes);
     UP(spheres, spheres);
     UP(planars, planars);
-    UP(prims, prims);
-    UP(materials, mats);
     UP(nodes32, nodes32);
     UP(boxes64, boxes64);
     UP(rec_user_id, rec_user_id);
@@ -317,10 +313,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     sc->d.nodes = sc->nodes.p;
     sc->d.spheres = sc->spheres.p;
     sc->d.planars = sc->planars.p;
-    sc->d.prims = sc->prims.p;
-    sc->d.materials = sc->materials.p;
     sc->d.n_nodes = n;
-    sc->d.n_prims = m;
     sc->d.filter_ok = filter_ok ? 1u : 0u;
     sc->d.nodes32 = sc->nodes32.p;
     sc->d.boxes64 = sc->boxes64.p;
@@ -517,7 +510,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         PathPool* pp = sc->lane(0);
         const uint32_t mode = lds_mode_for(sc, flags);
         const uint32_t waves = sc->n_cus * persistent_waves_per_cu(sc->d, mode);   // exactly what is resident at once
-        const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 23);   // 2048 slots per wave: a wave's round ends with a drain, so long rounds pay
+        const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 23);   // ~1600 slots per wave: a wave's round ends with a drain, so long rounds pay
         const uint64_t need = total < want ? total : want;
         uint32_t n_sub;
         uint64_t per_sub;

@@ -93,10 +93,7 @@ struct DScene {
     const DNode* nodes;
     const DSphere* spheres;
     const DPlanar* planars;
-    const DPrimInfo* prims;
-    const DMaterial* materials;
     uint32_t n_nodes;
-    uint32_t n_prims;
     uint32_t filter_ok;   // every box coordinate is finite and small enough for the filtered box test
     const DNode32* nodes32;
     const DBox64* boxes64;

@@ -29,9 +29,6 @@ constexpr int BLOCK = 256;
 constexpr int TRAVERSE_LDS_BLOCK = RTX_TRAVERSE_LDS_BLOCK;
 constexpr uint32_t MAX_BLOCK_WAVES = TRAVERSE_LDS_BLOCK / 64 > BLOCK / 64 ? TRAVERSE_LDS_BLOCK / 64 : BLOCK / 64;   // waves per block of the largest closest-hit launch
 
-#ifndef RTX_SPHERE_PREFETCH
-#define RTX_SPHERE_PREFETCH 0
-#endif
 #ifndef RTX_TRAVERSE_WAVES
 #define RTX_TRAVERSE_WAVES 1
 #endif
@@ -340,7 +337,6 @@ __global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene s
         bool searching = idx != NONE && node < end;
         bool pending = false;
         uint32_t leaf_kind = 0, leaf_slot = 0, leaf_prim = NONE;
-        double2 sph_a = make_double2(0.0, 0.0), sph_b = make_double2(0.0, 0.0);
         while (ballot64(searching) != 0ull) {
             if (searching) {
                 // the whole 64-byte record in four 16-byte loads issued back to back
@@ -366,13 +362,6 @@ __global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene s
                     leaf_prim = link.y;
                     leaf_kind = link.z;
                     leaf_slot = link.w;
-#if RTX_SPHERE_PREFETCH
-                    if (link.z == 0u) {   // start fetching the sphere while other lanes keep walking
-                        const double2* sp = reinterpret_cast<const double2*>(sc.spheres + link.w);
-                        sph_a = sp[0];
-                        sph_b = sp[1];
-                    }
-#endif
                 }
                 searching = !found && node < end;
             }
@@ -384,11 +373,8 @@ __global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene s
             bool ph;
             if (leaf_kind == 0u) {
                 if (COUNT) ++c_sph;
-#if !RTX_SPHERE_PREFETCH
                 const double2* spp = reinterpret_cast<const double2*>(sc.spheres + leaf_slot);
-                sph_a = spp[0];
-                sph_b = spp[1];
-#endif
+                const double2 sph_a = spp[0], sph_b = spp[1];
                 DSphere sp;
                 sp.c[0] = sph_a.x; sp.c[1] = sph_a.y; sp.c[2] = sph_b.x; sp.r = sph_b.y;
                 ph = sphere_t(sp, o, d, tmin, tmax, t);
@@ -974,9 +960,9 @@ __device__ __forceinline__ DHits uniform_hits(const DHits& h) {
 __device__ __forceinline__ DScene uniform_scene(const DScene& s) {
     DScene u = s;
     u.nodes = uniform_p(s.nodes); u.spheres = uniform_p(s.spheres); u.planars = uniform_p(s.planars);
-    u.prims = uniform_p(s.prims); u.materials = uniform_p(s.materials); u.nodes32 = uniform_p(s.nodes32);
+    u.nodes32 = uniform_p(s.nodes32);
     u.boxes64 = uniform_p(s.boxes64); u.shade_recs = uniform_p(s.shade_recs); u.rec_user_id = uniform_p(s.rec_user_id);
-    u.n_nodes = uniform32(s.n_nodes); u.n_prims = uniform32(s.n_prims); u.filter_ok = uniform32(s.filter_ok);
+    u.n_nodes = uniform32(s.n_nodes); u.filter_ok = uniform32(s.filter_ok);
     u.n_spheres = uniform32(s.n_spheres); u.n_planars = uniform32(s.n_planars);
     return u;
 }

@@ -47,8 +47,9 @@ def main():
             continue
         print(f"# {name}: building", file=sys.stderr, flush=True)
         t0 = time.perf_counter()
-        bvh = rt.HostBVH(surfaces, strategy)
+        bvh = rt.HostBVH(surfaces, strategy, device=True)   # the tree of the host builder, partitioned on the device
         build_s = time.perf_counter() - t0
+        bst = bvh.build_stats
         icam = rt.camera_initialize(cam)
         scene = rt.Scene(bvh)
         spp_nominal = icam.samples_per_pixel
@@ -67,7 +68,8 @@ def main():
         mean = float(acc.mean().item())
         print(json.dumps({
             "config": name, "image": f"{icam.image_width}x{icam.image_height}", "spp_nominal": spp_nominal, "spp_run": spp,
-            "surfaces": int(len(surfaces)), "bvh_nodes": bvh.n_nodes, "bvh_build_s_host": round(build_s, 3),
+            "surfaces": int(len(surfaces)), "bvh_nodes": bvh.n_nodes, "bvh_build_call_s": round(build_s, 3),
+            "bvh_build_device_ms": round(bst.ms_sort + bst.ms_levels, 3), "bvh_levels": bst.levels,
             "render_s": round(dt, 4), "render_s_at_nominal_spp": round(dt * spp_nominal / spp, 3),
             "paths": st.paths, "rays": st.rays, "rays_per_path": round(st.rays / st.paths, 3),
             "mrays_per_s": round(st.rays / dt / 1e6, 1), "rounds": st.iterations,
