@@ -9,11 +9,13 @@ HIPFLAGS ?= $(EXTRA) -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=o
 LIB  := raytracing_amd/librtx.so
 SRCS := raytracing_amd/csrc/rtx_kernels.hip raytracing_amd/csrc/rtx_build.hip raytracing_amd/csrc/rtx_output.hip raytracing_amd/csrc/rtx_api.cpp raytracing_amd/host/rtx_host.cpp
 OBJS := $(patsubst %,build/%.o,$(notdir $(SRCS)))
-HDRS := include/rtx.h include/rtx_host.h raytracing_amd/csrc/rtx_device.h raytracing_amd/csrc/rtx_kernels.h raytracing_amd/csrc/rtx_scan.h raytracing_amd/host/raytracing.hpp
+HDRS := include/rtx.h include/rtx_host.h raytracing_amd/csrc/rtx_device.h raytracing_amd/csrc/rtx_kernels.h raytracing_amd/csrc/rtx_scan.h raytracing_amd/host/raytracing.hpp raytracing_amd/host/examples.hpp
 vpath %.hip raytracing_amd/csrc
 vpath %.cpp raytracing_amd/csrc raytracing_amd/host
 
-all: $(LIB) oracle
+BIN  := bin/rtx_example
+
+all: $(LIB) $(BIN) oracle
 
 build/%.o: % $(HDRS)
 	@mkdir -p build
@@ -22,10 +24,15 @@ build/%.o: % $(HDRS)
 $(LIB): $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
 
+# the reference's `cargo run --example <name>` (host code only; links the library)
+$(BIN): examples/rtx_example.cpp raytracing_amd/host/examples.hpp raytracing_amd/host/raytracing.hpp include/rtx.h $(LIB)
+	@mkdir -p bin
+	g++ -O2 -std=c++17 -ffp-contract=off -Wall -o $@ examples/rtx_example.cpp -Lraytracing_amd -lrtx -Wl,-rpath,'$$ORIGIN/../raytracing_amd'
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -rf $(LIB) build
+	rm -rf $(LIB) build bin
 	$(MAKE) -C oracle clean
 .PHONY: all oracle clean

@@ -74,6 +74,15 @@ void rth_bvh_destroy(rth_bvh* bvh);
 /* Camera::initialize */
 int rth_camera_initialize(const rtx_camera_config* cfg, rtx_camera* out);
 
+/* The scene and camera of one of the reference's example programs
+ * (examples/<name>.rs: hello_triangle, cover_spheres, cornell_box, quads,
+ * simple_light, simple_scene, demo_spheres), as its main() hands them to
+ * RenderRunner.  cover_spheres draws its scene at random; scene_seed makes
+ * that repeatable.  surfaces may be NULL to ask for the count only; at most
+ * `capacity` records are written, *n is the scene's size. */
+int rth_example(const char* name, uint64_t scene_seed, rtx_surface* surfaces, uint32_t capacity, uint32_t* n,
+                rtx_camera_config* cfg);
+
 /* RenderRunner::run (src/runner.rs:23-41) on the current HIP device:
  * build, render, write a P3 PPM to `ppm_path` (NULL: no image file) and the
  * linear image to out_rgb ([H][W][3], may be NULL). */

@@ -107,7 +107,7 @@ ABI_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_trace_closest",
     "rtx_primary_rays", "rtx_render_accumulate", "rtx_scale", "rtx_quantize", "rtx_render", "rtx_selftest_math",
     "rtx_selftest_rng", "rtx_bvh_build", "rtx_ppm_text_bound", "rtx_ppm_text", "rtx_render_ppm",
-    "rth_last_error", "rth_bvh_build", "rth_bvh_build_device", "rth_run_device_build", "rth_bvh_desc", "rth_bvh_destroy", "rth_camera_initialize", "rth_run",
+    "rth_last_error", "rth_bvh_build", "rth_bvh_build_device", "rth_run_device_build", "rth_example", "rth_bvh_desc", "rth_bvh_destroy", "rth_camera_initialize", "rth_run",
 ]
 
 _lib.rtx_last_error.restype = C.c_char_p
@@ -132,6 +132,7 @@ _lib.rtx_ppm_text_bound.argtypes = [C.c_uint32, C.c_uint32]
 _lib.rtx_ppm_text_bound.restype = C.c_uint64
 _lib.rtx_ppm_text.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, _p(C.c_uint64), C.c_void_p]
 _lib.rtx_render_ppm.argtypes = [C.c_void_p, _p(Camera), C.c_uint64, C.c_uint32, _dp, C.c_char_p, C.c_uint64, _p(C.c_uint64), _p(Stats)]
+_lib.rth_example.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, _p(C.c_uint32), _p(CameraConfig)]
 _lib.rth_bvh_desc.argtypes = [C.c_void_p, _p(SceneDesc)]
 _lib.rth_bvh_desc.restype = None
 _lib.rth_bvh_destroy.argtypes = [C.c_void_p]
@@ -204,6 +205,16 @@ def bvh_build_device(leaf_boxes, strategy=SAH_PER_SURFACE, buckets=0):
     _check(_lib.rtx_bvh_build(_ptr(boxes, _dp), n, strategy, buckets, _ptr(order, _u32p), _ptr(bmin, _dp), _ptr(bmax, _dp),
                               _ptr(right, _u32p), _ptr(prim, _u32p), C.byref(st)))
     return order, bmin, bmax, right, prim, st
+
+
+def example(name, scene_seed=0xC0FFEE):
+    """``rth_example``: (surfaces, CameraConfig) of one of the reference's example programs, built by the C++ host API."""
+    n = C.c_uint32(0)
+    cfg = CameraConfig()
+    _check(_lib.rth_example(name.encode(), scene_seed, None, 0, C.byref(n), C.byref(cfg)), host=True)
+    surfaces = np.zeros(n.value, SURFACE_DTYPE)
+    _check(_lib.rth_example(name.encode(), scene_seed, surfaces.ctypes.data_as(C.c_void_p), n.value, C.byref(n), C.byref(cfg)), host=True)
+    return surfaces, cfg
 
 
 class HostBVH:

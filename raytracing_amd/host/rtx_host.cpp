@@ -1,6 +1,7 @@
 // rtx_host.cpp -- C entry points over raytracing.hpp (see include/rtx_host.h).
 #include "../../include/rtx_host.h"
 #include "raytracing.hpp"
+#include "examples.hpp"
 
 #include <string>
 
@@ -109,6 +110,52 @@ int rth_camera_initialize(const rtx_camera_config* cfg, rtx_camera* out) {
     }
     *out = to_camera(*cfg).initialize();
     return RTX_OK;
+}
+
+int rth_example(const char* name, uint64_t scene_seed, rtx_surface* surfaces, uint32_t capacity, uint32_t* n, rtx_camera_config* cfg) {
+    if (!name || !n || !cfg) {
+        g_err = "rth_example: null argument";
+        return RTX_ERR_BAD_ARG;
+    }
+    try {
+        const examples::Example e = examples::by_name(name, scene_seed);
+        *n = (uint32_t)e.surfaces.size();
+        for (uint32_t i = 0; surfaces && i < *n && i < capacity; ++i) {
+            const Surface& s = e.surfaces[i];
+            rtx_surface& o = surfaces[i];
+            std::memset(&o, 0, sizeof o);
+            o.geom_kind = (uint32_t)s.geometry.kind;
+            o.mat_kind = (uint32_t)s.material.kind;
+            const Vector3 q = s.geometry.kind == Geometry::Sphere ? s.geometry.center : s.geometry.q;
+            for (int a = 0; a < 3; ++a) {
+                o.q[a] = q[a];
+                o.u[a] = s.geometry.u[a];
+                o.v[a] = s.geometry.v[a];
+                o.rgb[a] = s.material.rgb[a];
+            }
+            o.radius = s.geometry.radius;
+            o.param = s.material.param;
+        }
+        const Camera& c = e.camera;
+        std::memset(cfg, 0, sizeof *cfg);
+        cfg->aspect_ratio = c.aspect_ratio;
+        cfg->image_width = c.image_width;
+        cfg->samples_per_pixel = c.samples_per_pixel;
+        cfg->max_depth = c.max_depth;
+        cfg->v_fov = c.v_fov;
+        for (int a = 0; a < 3; ++a) {
+            cfg->look_from[a] = c.look_from[a];
+            cfg->look_at[a] = c.look_at[a];
+            cfg->v_up[a] = c.v_up[a];
+            cfg->background[a] = c.background[a];
+        }
+        cfg->defocus_angle = c.defocus_angle;
+        cfg->focus_dist = c.focus_dist;
+        return RTX_OK;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return RTX_ERR_BAD_ARG;
+    }
 }
 
 static int run_impl(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, const rtx_camera_config* cfg,

@@ -400,3 +400,26 @@ def test_runner_writes_the_references_ppm(rt, oracle, tmp_path):
                          img.ctypes.data_as(C.POINTER(C.c_double)))
     assert rc == 0, rt._lib.rth_last_error()
     assert path.read_bytes() == expected_ppm(oracle, img)
+
+
+def test_example_program_prints_the_runners_ppm(rt, oracle, tmp_path):
+    """bin/rtx_example (the reference's `cargo run --example`): stdout is the P3 text of the image
+    rth_run returns for the same scene, camera and seed."""
+    import ctypes as C
+    import subprocess
+
+    surfaces, cfg = rt.example("simple_scene")
+    cfg.image_width, cfg.samples_per_pixel = 96, 3
+    icam = rt.camera_initialize(cfg)
+    img = np.zeros((icam.image_height, icam.image_width, 3))
+    assert rt._lib.rth_run(surfaces.ctypes.data_as(C.c_void_p), len(surfaces), 3, 0, C.byref(cfg), 9, None,
+                           img.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    for build in ("host", "device"):
+        p = subprocess.run([os.path.join(ROOT, "bin", "rtx_example"), "simple_scene", "--width", "96", "--spp", "3", "--seed", "9", "--build", build],
+                           capture_output=True, timeout=120)
+        assert p.returncode == 0, p.stderr.decode()
+        assert b"BVH construction" in p.stderr and b"Rendering" in p.stderr
+        got = np.array(p.stdout.split()[4:], dtype=np.int64).reshape(img.shape)
+        want = oracle.ppm_quantize(img.reshape(-1, 3)).reshape(img.shape)
+        assert p.stdout.startswith(b"P3\n96 54\n255\n")
+        assert np.abs(got - want).max() <= 1   # the two runs add the same radiance values in different orders

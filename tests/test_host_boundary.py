@@ -120,3 +120,40 @@ def test_render_api_rejects_bad_arguments_without_a_device(rt):
     bad.n_nodes = 1
     out = ctypes.c_void_p()
     assert lib.rtx_scene_create(ctypes.byref(bad), ctypes.byref(out)) == -1
+
+
+@pytest.mark.parametrize("name", list(S.EXAMPLES))
+def test_cpp_example_scenes_equal_the_python_ones(rt, name):
+    """The C++ scene constructors (raytracing_amd/host/examples.hpp, through rth_example) and
+    raytracing_amd/scenes.py are two statements of the same example files: same surfaces in the
+    same order, bit for bit, and the same camera."""
+    surfaces, cfg = rt.example(name)
+    want, cam = S.EXAMPLES[name]()
+    assert len(surfaces) == len(want)
+    for field in rt.SURFACE_DTYPE.names:
+        a, b = np.ascontiguousarray(surfaces[field]), np.ascontiguousarray(want[field])
+        if a.dtype == np.float64:
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), field
+        else:
+            assert np.array_equal(a, b), field
+    wcfg = rt.camera_config(cam)
+    assert bytes(cfg) == bytes(wcfg)
+
+
+def test_cpp_example_errors_and_seed(rt):
+    with pytest.raises(rt.RtxError):
+        rt.example("no_such_example")
+    a, _ = rt.example("cover_spheres", 1)
+    b, _ = rt.example("cover_spheres", 2)
+    w, _ = S.cover_spheres(seed=2)
+    assert not np.array_equal(a["q"][:10], b["q"][:10])
+    assert np.array_equal(b["q"], w["q"])
+
+
+def test_example_program_lists_the_examples():
+    import subprocess
+
+    exe = os.path.join(ROOT, "bin", "rtx_example")
+    out = subprocess.run([exe, "--list"], capture_output=True, text=True, check=True).stdout.split()
+    assert out == list(S.EXAMPLES)
+    assert subprocess.run([exe, "nope"], capture_output=True).returncode == 1
