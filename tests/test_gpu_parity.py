@@ -408,6 +408,8 @@ def test_example_program_prints_the_runners_ppm(rt, oracle, tmp_path):
     import ctypes as C
     import subprocess
 
+    if not os.path.exists(os.path.join(ROOT, "bin", "rtx_example")):
+        pytest.skip("bin/rtx_example is not built (run make)")
     surfaces, cfg = rt.example("simple_scene")
     cfg.image_width, cfg.samples_per_pixel = 96, 3
     icam = rt.camera_initialize(cfg)

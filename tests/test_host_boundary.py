@@ -154,6 +154,8 @@ def test_example_program_lists_the_examples():
     import subprocess
 
     exe = os.path.join(ROOT, "bin", "rtx_example")
+    if not os.path.exists(exe):
+        pytest.skip("bin/rtx_example is not built (run make)")
     out = subprocess.run([exe, "--list"], capture_output=True, text=True, check=True).stdout.split()
     assert out == list(S.EXAMPLES)
     assert subprocess.run([exe, "nope"], capture_output=True).returncode == 1
