@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Benchmark: Mrays/s (all bounces) and wall time of cover_spheres at
-1920x1080, 500 samples per pixel -- the metric BASELINE.json names.
+1920x1080, 500 samples per pixel -- the headline metric.
 
 One step = one full render of that frame.  Inputs (the flattened BVH) are
 resident in HBM before the timed region; the step covers clearing the
@@ -45,6 +45,24 @@ def measured_traffic(kernel):
         return recs[name]["hbm_bytes_per_launch"], "profiles/hbm_traffic.json: " + recs[name].get("source", "")
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def measured_valu_issue(kernel):
+    """Share of SIMD cycles issuing vector-ALU instructions and share of lanes active in them, for `kernel`,
+    from the committed rocprofv3 PMC passes (counters cannot be collected from inside this process)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as fh:
+            recs = json.load(fh)["kernels"]
+        name = max((k for k in recs if k.split("<")[0] == kernel), key=lambda k: recs[k].get("SQ_WAVES", 0))
+        c = recs[name]
+        xcd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0           # summed over the 8 XCDs
+        return {
+            "busy_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (xcd_cycles * 1024.0), 3),   # 4 cycles per instruction, 1024 SIMDs
+            "lanes_active_frac": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 3),
+            "source": "profiles/r01_pmc_summary.json (SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE, SQ_THREAD_CYCLES_VALU)",
+        }
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
 
 
 def cpu_baseline(surfaces, cam, target_s=15.0):
@@ -219,12 +237,14 @@ def main():
                         "reach HBM (traffic): the kernel is bound by VALU issue and divergence; see valu_f64",
                 "valu_f64": {"achieved_tflops": round(achieved_tf, 3), "peak_tflops": FP64_VECTOR_PEAK_TF,
                              "frac": round(achieved_tf / FP64_VECTOR_PEAK_TF, 4), "flops_per_ray": round(flops_per_ray, 1)},
+                "valu_issue": measured_valu_issue(kernel),
                 "rounds_of_busiest_wave": int(max(s.iterations for s in stats)),
-                "kernel_time_share": {"traverse_ms": round(sum(s.ms_traverse for s in stats) / args.steps, 2),
-                                      "shade_ms": round(sum(s.ms_shade for s in stats) / args.steps, 2),
-                                      "generate_ms": round(sum(s.ms_generate for s in stats) / args.steps, 2)},
             },
         }
+        if args.time_kernels:   # round-loop path: summed launch durations per kernel
+            out["roofline"]["kernel_time_share"] = {"traverse_ms": round(sum(s.ms_traverse for s in stats) / args.steps, 2),
+                                                    "shade_ms": round(sum(s.ms_shade for s in stats) / args.steps, 2),
+                                                    "generate_ms": round(sum(s.ms_generate for s in stats) / args.steps, 2)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(surfaces, cam)
             out["speedup_vs_cpu_baseline"] = round(mrays / out["cpu_baseline"]["value"], 1)
