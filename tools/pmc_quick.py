@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """One rocprofv3 --pmc pass with the counters given on the command line:
-    python3 tools/pmc_quick.py OUTDIR COUNTER[,COUNTER...] [bench args...]
-Prints per-kernel totals."""
+    python3 tools/pmc_quick.py OUTDIR COUNTER[,COUNTER...] [bench args... | SCRIPT.py args...]
+Profiles bench.py, or another script when the first extra argument ends in .py.  Prints per-kernel totals."""
 import csv, glob, os, subprocess, sys
 out, ctrs = sys.argv[1], sys.argv[2].split(",")
 bench_args = sys.argv[3:] or ["--spp", "60", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
-cmd = ["timeout", "-s", "KILL", "240", "rocprofv3", "--pmc", *ctrs, "--output-format", "csv", "-d", out, "--", "python3", "bench.py", *bench_args]
+script = ["bench.py"] if not bench_args[0].endswith(".py") else []
+cmd = ["timeout", "-s", "KILL", "240", "rocprofv3", "--pmc", *ctrs, "--output-format", "csv", "-d", out, "--", "python3", *script, *bench_args]
 r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 if r.returncode != 0:
     print("failed", r.returncode, r.stdout[-600:]); sys.exit(1)
