@@ -306,6 +306,15 @@ __device__ __forceinline__ double first_uniform_of_block(uint32_t k0, uint32_t k
     const uint64_t w0 = ((uint64_t)o[1] << 32) | o[0];
     return (double)(w0 >> 11) * 0x1.0p-53;
 }
+// Both uniforms of block `blk` of a stream (draws 2*blk and 2*blk + 1)
+__device__ __forceinline__ void uniforms_of_block(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk, double& u0, double& u1) {
+    uint32_t o[4];
+    philox4x32_10(pixel, sample, blk, 0u, k0, k1, o);
+    const uint64_t w0 = ((uint64_t)o[1] << 32) | o[0];
+    const uint64_t w1 = ((uint64_t)o[3] << 32) | o[2];
+    u0 = (double)(w0 >> 11) * 0x1.0p-53;
+    u1 = (double)(w1 >> 11) * 0x1.0p-53;
+}
 // src/vector.rs:83-95
 __device__ __forceinline__ V3 random_in_unit_disk(PathRng& rng) {
     for (;;) {

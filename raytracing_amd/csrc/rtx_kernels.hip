@@ -91,6 +91,93 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+// ---------------------------------------------------------------- rejection samplers, as a wave
+// The reference's rejection loops (Vector3::random_unit, src/vector.rs:59-81,
+// accepts 52 % of its candidates; random_in_unit_disk, src/vector.rs:83-95,
+// 79 %) run by 64 lanes in lockstep wait for the unluckiest lane (6-7 rounds
+// for 1.9 useful trials of random_unit).  Here every lane with `need` first
+// tries its own trial 0; after that the lanes between two unresolved lanes all
+// work for the upper one, each on a different one of its next trials, and the
+// lowest accepted trial wins.  Trial k of a ray is Philox block blk0 + k of its
+// stream whichever lane computes it, so the accepted candidate and the number
+// of trials are exactly those of the sequential loop.  Must be called by all
+// 64 lanes.  Returns the accepted candidate and the number of trials used.
+// Sampler: static V3 candidate(k0, k1, pixel, sample, blk); static bool accept(V3).
+struct UnitVectorTrial {   // one trial of Vector3::random_unit (the candidate is not normalised)
+    static __device__ __forceinline__ V3 candidate(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk) {
+        return random_unit_candidate(k0, k1, pixel, sample, blk);
+    }
+    static __device__ __forceinline__ bool accept(const V3& c) {
+        const double l = length_squared(c);
+        return 1e-160 < l && l <= 1.0;
+    }
+};
+struct UnitDiskTrial {   // one trial of Vector3::random_in_unit_disk: x, y = random_range(-1.0..1.0) from the two words of a block
+    static __device__ __forceinline__ V3 candidate(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk) {
+        double u0, u1;
+        uniforms_of_block(k0, k1, pixel, sample, blk, u0, u1);
+        return v3(u0 * 2.0 + -1.0, u1 * 2.0 + -1.0, 0.0);
+    }
+    static __device__ __forceinline__ bool accept(const V3& c) { return length_squared(c) < 1.0; }
+};
+template <class Sampler>
+__device__ __forceinline__ void rejection_wave(bool need, uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk0,
+                                               V3& cand, uint32_t& used) {
+    const uint32_t lane = lane_id();
+    cand = v3(1.0, 0.0, 0.0);
+    used = 0u;
+    uint32_t tried = 0;   // trials of this lane's own ray that have failed so far
+    bool unresolved = need;
+    if (need) {
+        const V3 c = Sampler::candidate(k0, k1, pixel, sample, blk0);
+        tried = 1u;
+        if (Sampler::accept(c)) {
+            cand = c;
+            used = 1u;
+            unresolved = false;
+        }
+    }
+    unsigned long long U = ballot64(unresolved);
+    while (U != 0ull) {
+        // the unresolved lane at or above this one, and how many lanes lie between it and the unresolved lane below
+        const unsigned long long at_or_above = U >> lane;
+        const bool helping = at_or_above != 0ull;
+        const uint32_t target = helping ? lane + (uint32_t)__builtin_ctzll(at_or_above) : lane;
+        const unsigned long long below = U & ((1ull << lane) - 1ull);                      // unresolved lanes under this one
+        const uint32_t first_helper = below ? 64u - (uint32_t)__builtin_clzll(below) : 0u;   // lane after the unresolved lane below
+        const uint32_t q = lane - first_helper;                                              // this lane's trial offset for the target
+        const uint32_t t_pixel = __shfl(pixel, (int)target, 64), t_sample = __shfl(sample, (int)target, 64);
+        const uint32_t t_blk = __shfl(blk0 + tried, (int)target, 64);
+        bool ok = false;
+        V3 c = v3(0.0, 0.0, 0.0);
+        if (helping) {
+            c = Sampler::candidate(k0, k1, t_pixel, t_sample, t_blk + q);
+            ok = Sampler::accept(c);
+        }
+        const unsigned long long okmask = ballot64(ok);
+        // an unresolved lane looks at its helpers: lanes first_helper .. lane
+        const unsigned long long mine = unresolved ? (okmask >> first_helper) & (~0ull >> (63u - (lane - first_helper))) : 0ull;
+        const bool got = mine != 0ull;
+        const uint32_t win_q = got ? (uint32_t)__builtin_ctzll(mine) : 0u;
+        const int src = (int)(first_helper + win_q);
+        const double cx = __shfl(c.x, src, 64), cy = __shfl(c.y, src, 64), cz = __shfl(c.z, src, 64);
+        if (unresolved) {
+            if (got) {
+                cand = v3(cx, cy, cz);
+                used = tried + win_q + 1u;
+                unresolved = false;
+            } else {
+                tried += lane - first_helper + 1u;   // all of this round's helpers failed
+            }
+        }
+        U = ballot64(unresolved);
+    }
+}
+__device__ __forceinline__ void random_unit_wave(bool need, uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk0,
+                                                 V3& cand, uint32_t& used) {
+    rejection_wave<UnitVectorTrial>(need, k0, k1, pixel, sample, blk0, cand, used);
+}
+
 // ---------------------------------------------------------------- primary rays
 // sample_square + get_ray, src/camera.rs:164-182.
 __device__ __forceinline__ void start_path(const DCamera& cam, uint64_t seed, uint32_t pixel, uint32_t sample,
@@ -110,6 +197,29 @@ __device__ __forceinline__ void start_path(const DCamera& cam, uint64_t seed, ui
     }
     direction = pixel_sample - origin;
     draw = rng.draw;
+}
+
+// The same for the 64 paths of a wave at once (lanes without `valid` only help): the defocus disk's
+// rejection loop is shared out over the wave.  Bit-identical to start_path.  Must be called by all 64 lanes.
+__device__ __forceinline__ void start_path_wave(const DCamera& cam, uint64_t seed, bool valid, uint32_t pixel, uint32_t sample,
+                                                V3& origin, V3& direction, uint32_t& draw) {
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    double u0, u1;
+    uniforms_of_block(k0, k1, pixel, sample, 0u, u0, u1);   // sample_square: draws 0 and 1
+    const uint32_t row = pixel / cam.image_width;
+    const uint32_t col = pixel - row * cam.image_width;
+    const double ox = u0 - 0.5, oy = u1 - 0.5;
+    const V3 pixel_sample = ld3(cam.pixel00_loc) + (((double)col + ox) * ld3(cam.pixel_du)) + (((double)row + oy) * ld3(cam.pixel_dv));
+    origin = ld3(cam.center);
+    draw = 2u;
+    if (cam.defocus_angle > 0.0) {   // wave-uniform
+        V3 p;
+        uint32_t trials;
+        rejection_wave<UnitDiskTrial>(valid, k0, k1, pixel, sample, 1u, p, trials);   // a new sampling event: block 1 on
+        origin = ld3(cam.center) + (p.x * ld3(cam.defocus_disk_u)) + (p.y * ld3(cam.defocus_disk_v));
+        draw = 2u + 2u * trials;
+    }
+    direction = pixel_sample - origin;
 }
 
 // Path g of a render call is sample (spp_begin + g / npix) of the pixel that
@@ -154,13 +264,16 @@ __device__ __forceinline__ void split_path_index(unsigned long long g, unsigned 
 __device__ __forceinline__ void generate_wave(const DCamera& cam, const DState& st, uint32_t slot0, unsigned long long first, uint32_t n_new,
                                               uint64_t seed, uint32_t spp_begin) {
     const unsigned long long npix = (unsigned long long)cam.image_width * cam.image_height;
-    for (uint32_t i = lane_id(); i < n_new; i += 64u) {
+    for (uint32_t i0 = 0; i0 < n_new; i0 += 64u) {   // whole rows: the lanes past the end help the others
+        const uint32_t i = i0 + lane_id();
+        const bool valid = i < n_new;
         uint32_t pixel, sample_off;
-        split_path_index(first + i, npix, pixel, sample_off);
+        split_path_index(first + (valid ? i : 0u), npix, pixel, sample_off);
         const uint32_t sample = spp_begin + sample_off;
         V3 o, d;
         uint32_t draw;
-        start_path(cam, seed, pixel, sample, o, d, draw);
+        start_path_wave(cam, seed, valid, pixel, sample, o, d, draw);
+        if (!valid) continue;
         const uint32_t k = slot0 + i;
         st.ox[k] = o.x; st.oy[k] = o.y; st.oz[k] = o.z;
         st.dx[k] = d.x; st.dy[k] = d.y; st.dz[k] = d.z;
@@ -680,71 +793,6 @@ __device__ __forceinline__ double reflectance(double cos_theta, double refractio
     double x2 = x * x;
     double x5 = x * (x2 * x2);
     return r0 + (1.0 - r0) * x5;
-}
-
-// Vector3::random_unit() (src/vector.rs:59-81) for the lanes with `need`, as a
-// wave.  The reference's loop accepts 52 % of its candidates, so 64 lanes
-// looping in lockstep wait for the unluckiest one (6-7 rounds for 1.9 useful
-// trials).  Here every lane first tries its own trial 0; after that the lanes
-// between two unresolved lanes all work for the upper one, each on a
-// different one of its next trials, and the lowest accepted trial wins.  Trial
-// k of a ray is Philox block blk0 + k of its stream whichever lane computes
-// it, so the accepted candidate and the number of trials are exactly those of
-// the sequential loop.  Must be called by all 64 lanes.  Returns the accepted
-// candidate (not normalised) and the number of trials used.
-__device__ __forceinline__ void random_unit_wave(bool need, uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk0,
-                                                 V3& cand, uint32_t& used) {
-    const uint32_t lane = lane_id();
-    cand = v3(1.0, 0.0, 0.0);
-    used = 0u;
-    uint32_t tried = 0;   // trials of this lane's own ray that have failed so far
-    bool unresolved = need;
-    if (need) {
-        const V3 c = random_unit_candidate(k0, k1, pixel, sample, blk0);
-        const double l = length_squared(c);
-        tried = 1u;
-        if (1e-160 < l && l <= 1.0) {
-            cand = c;
-            used = 1u;
-            unresolved = false;
-        }
-    }
-    unsigned long long U = ballot64(unresolved);
-    while (U != 0ull) {
-        // the unresolved lane at or above this one, and how many lanes lie between it and the unresolved lane below
-        const unsigned long long at_or_above = U >> lane;
-        const bool helping = at_or_above != 0ull;
-        const uint32_t target = helping ? lane + (uint32_t)__builtin_ctzll(at_or_above) : lane;
-        const unsigned long long below = U & ((1ull << lane) - 1ull);                      // unresolved lanes under this one
-        const uint32_t first_helper = below ? 64u - (uint32_t)__builtin_clzll(below) : 0u;   // lane after the unresolved lane below
-        const uint32_t q = lane - first_helper;                                              // this lane's trial offset for the target
-        const uint32_t t_pixel = __shfl(pixel, (int)target, 64), t_sample = __shfl(sample, (int)target, 64);
-        const uint32_t t_blk = __shfl(blk0 + tried, (int)target, 64);
-        bool ok = false;
-        V3 c = v3(0.0, 0.0, 0.0);
-        if (helping) {
-            c = random_unit_candidate(k0, k1, t_pixel, t_sample, t_blk + q);
-            const double l = length_squared(c);
-            ok = 1e-160 < l && l <= 1.0;
-        }
-        const unsigned long long okmask = ballot64(ok);
-        // an unresolved lane looks at its helpers: lanes first_helper .. lane
-        const unsigned long long mine = unresolved ? (okmask >> first_helper) & (~0ull >> (63u - (lane - first_helper))) : 0ull;
-        const bool got = mine != 0ull;
-        const uint32_t win_q = got ? (uint32_t)__builtin_ctzll(mine) : 0u;
-        const int src = (int)(first_helper + win_q);
-        const double cx = __shfl(c.x, src, 64), cy = __shfl(c.y, src, 64), cz = __shfl(c.z, src, 64);
-        if (unresolved) {
-            if (got) {
-                cand = v3(cx, cy, cz);
-                used = tried + win_q + 1u;
-                unresolved = false;
-            } else {
-                tried += lane - first_helper + 1u;   // all of this round's helpers failed
-            }
-        }
-        U = ballot64(unresolved);
-    }
 }
 
 // Sphere u,v (geometry.rs:236-240), from the world-space point as the reference has it.  Out of line: no
