@@ -247,12 +247,15 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     bool f32_ok = true;
     std::vector<uint32_t> miss(n, NONE);
     bool filter_ok = true;
+    uint32_t thin_nodes = 0;   // boxes with a side that single precision barely resolves (flat walls far from the origin)
     if (n) miss[0] = n;
     for (uint32_t i = 0; i < n; ++i) {
         DNode& nd = nodes[i];
+        bool thin = false;
         for (int a = 0; a < 3; ++a) {
             nd.bmin[a] = desc->node_bmin[(size_t)a * n + i];
             nd.bmax[a] = desc->node_bmax[(size_t)a * n + i];
+            if (nd.bmax[a] - nd.bmin[a] <= 0x1.0p-16 * std::fmax(std::fabs(nd.bmin[a]), std::fabs(nd.bmax[a]))) thin = true;
             if (!(std::fabs(nd.bmin[a]) <= 0x1.0p300) || !(std::fabs(nd.bmax[a]) <= 0x1.0p300)) filter_ok = false;
             if (!(std::fabs(nd.bmin[a]) <= 1e15) || !(std::fabs(nd.bmax[a]) <= 1e15)) f32_ok = false;
             boxes64[i].bmin[a] = nd.bmin[a];
@@ -260,6 +263,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
             nodes32[i].plane[2 * a] = (float)nd.bmin[a];
             nodes32[i].plane[2 * a + 1] = (float)nd.bmax[a];
         }
+        if (thin) ++thin_nodes;
         if (miss[i] == NONE) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: node " + std::to_string(i) + " is not reachable in pre-order");
         if (miss[i] <= i || miss[i] > n) return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: malformed tree");
         nd.miss = miss[i];
@@ -315,6 +319,9 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     sc->d.planars = sc->planars.p;
     sc->d.n_nodes = n;
     sc->d.filter_ok = filter_ok ? 1u : 0u;
+    // Many box tests of such a scene are left to the f64 tiers: the walk then collects those lanes and resolves
+    // them together instead of one by one inside its loop (RTX_BATCH_F64_BOXES=0/1 overrides the choice).
+    sc->d.batch_undecided = env_u32("RTX_BATCH_F64_BOXES", (uint64_t)thin_nodes * 20u >= n ? 1u : 0u, true);
     sc->d.nodes32 = sc->nodes32.p;
     sc->d.boxes64 = sc->boxes64.p;
     sc->d.n_spheres = n_spheres;

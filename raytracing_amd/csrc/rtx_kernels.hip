@@ -545,7 +545,7 @@ struct WorkCounters {
     unsigned long long nodes = 0, spheres = 0, planars = 0, fallbacks = 0;
 };
 
-template <bool COUNT, bool LDS_NODES, bool SHARED>
+template <bool COUNT, bool LDS_NODES, bool SHARED, bool BATCH>
 __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState& rays, const DHits& hits, const TraverseWork& w, double tmin,
                                                   double tmax0, DRenderCtl* ctl, WorkCounters& wc) {
     const uint32_t lane = lane_id();
@@ -555,6 +555,7 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
     bool list_done = p_end == 0u;
     uint32_t next_p = 0;   // !SHARED: next position of the wave's own list
     const bool scene_filter = sc.filter_ok != 0u;
+    constexpr bool batch_undecided = BATCH;   // a separate instance of the kernel: with both forms in one loop the common one is 3 % slower
     const uint32_t end = sc.n_nodes * 32u;   // nodes are addressed by the byte offset of their 32-byte record
 
     uint32_t idx = NONE;   // ray of this lane, NONE = idle
@@ -612,10 +613,11 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
         ++pt_outer;
 #endif
         // ---- phase 1: walk to the next leaf whose box is hit
-        // (a lane that found its leaf waits; the loop also ends as soon as
-        // PEND_AT lanes are waiting, so a few long searches do not stall them)
+        // (a lane that found its leaf waits; so does a lane whose box test the f32 tier could not decide, at
+        // that node; the loop also ends as soon as PEND_AT lanes are waiting, so a few long searches do not stall them)
         uint32_t n_pending = 0;   // wave-uniform
         bool searching = idx != NONE && node < end;
+        bool undecided = false;
         while (searching) {       // lanes leave the loop one by one; the wave stays until all have left
             uint4 n0, n1;
             if (LDS_NODES) {
@@ -631,33 +633,43 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
             const float planes[6] = {__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z),
                                      __uint_as_float(n0.w), __uint_as_float(n1.x), __uint_as_float(n1.y)};
             bool hit;
-#ifdef RTX_PROFILE_PHASES
-            const bool decided_ = box_hit_f32(planes, rf, hit);
-            const long long fb0_ = clock64();
-            if (ballot64(!decided_) != 0ull) ++pt_fb_iters;
-            if (!decided_) {
-#else
-            if (!box_hit_f32(planes, rf, hit)) {   // undecided in f32: the exact box, f64 filter, then the division form
-#endif
+            bool decided = box_hit_f32(planes, rf, hit);
+            if (!decided && !batch_undecided) {   // few such tests in this scene: the exact box, f64 filter, then the division form, here
                 const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> 5));
                 const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
                 if (COUNT) ++c_fallback;
                 hit = tier2_box(q0, q1, q2, o, d, tmin, tmax, scene_filter);
+                decided = true;
             }
-#ifdef RTX_PROFILE_PHASES
-            pt_fb_cycles += clock64() - fb0_;
-#endif
             const bool is_leaf = n1.w != NONE;
-            const bool found = hit && is_leaf;
-            node = (hit && !is_leaf) ? node + 32u : n1.z;   // links are byte offsets; a leaf's successor is its miss link as well
+            const bool found = decided && hit && is_leaf;
+            if (decided) node = (hit && !is_leaf) ? node + 32u : n1.z;   // links are byte offsets; a leaf's successor is its miss link as well
             leaf = found ? n1.w : leaf;
             pending = found;
-            n_pending += (uint32_t)__popcll(ballot64(found));
-            searching = !found && node < end;
+            undecided = !decided;
+            n_pending += (uint32_t)__popcll(ballot64(found || !decided));
+            searching = decided && !found && node < end;
 #ifdef RTX_PROFILE_PHASES
             ++pt_iters;
 #endif
             if (n_pending >= PEND_AT) break;   // wave-uniform
+        }
+        // ---- phase 1b (scenes with many such tests): the boxes left undecided, for all waiting lanes together
+        if (undecided) {
+#ifdef RTX_PROFILE_PHASES
+            ++pt_fb_iters;
+#endif
+            const uint4 n1 = LDS_NODES ? reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + node)[1]
+                                       : reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + node)[1];
+            const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> 5));
+            const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
+            if (COUNT) ++c_fallback;
+            const bool hit = tier2_box(q0, q1, q2, o, d, tmin, tmax, scene_filter);
+            const bool is_leaf = n1.w != NONE;
+            pending = hit && is_leaf;
+            node = (hit && !is_leaf) ? node + 32u : n1.z;
+            leaf = pending ? n1.w : leaf;
+            undecided = false;
         }
         PT(pt_p1);
 
@@ -725,7 +737,7 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
     }
 }
 
-template <bool COUNT, bool LDS_NODES>
+template <bool COUNT, bool LDS_NODES, bool BATCH>
 __global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_traverse_f32(DScene sc, DState rays, DHits hits, DPool pool,
                                                                                        double tmin, double tmax0, DRenderCtl* ctl,
                                                                                        uint32_t lds_surfaces) {
@@ -775,7 +787,7 @@ __global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_trav
     w.first_pool = first_pool;
     w.sub_capacity = pool.sub_capacity;
     WorkCounters wc;
-    traverse_f32_wave<COUNT, LDS_NODES, true>(sc, rays, hits, w, tmin, tmax0, ctl, wc);
+    traverse_f32_wave<COUNT, LDS_NODES, true, BATCH>(sc, rays, hits, w, tmin, tmax0, ctl, wc);
     if (COUNT && ctl) {
         atomicAdd(&ctl->node_visits, wc.nodes);
         atomicAdd(&ctl->sphere_tests, wc.spheres);
@@ -1010,7 +1022,7 @@ __device__ __forceinline__ DScene uniform_scene(const DScene& s) {
     u.nodes = uniform_p(s.nodes); u.spheres = uniform_p(s.spheres); u.planars = uniform_p(s.planars);
     u.nodes32 = uniform_p(s.nodes32);
     u.boxes64 = uniform_p(s.boxes64); u.shade_recs = uniform_p(s.shade_recs); u.rec_user_id = uniform_p(s.rec_user_id);
-    u.n_nodes = uniform32(s.n_nodes); u.filter_ok = uniform32(s.filter_ok);
+    u.n_nodes = uniform32(s.n_nodes); u.filter_ok = uniform32(s.filter_ok); u.batch_undecided = uniform32(s.batch_undecided);
     u.n_spheres = uniform32(s.n_spheres); u.n_planars = uniform32(s.n_planars);
     return u;
 }
@@ -1022,7 +1034,7 @@ __device__ __noinline__ void phase_generate(const DRenderParams* pp, uint32_t pa
     first = uniform64(first);
     generate_wave(P->cam, uniform_state(P->st[parity]), slot0, first, got, uniform64(P->seed), uniform32(P->spp_begin));
 }
-template <bool COUNT, bool LDS_NODES>
+template <bool COUNT, bool LDS_NODES, bool BATCH>
 __device__ __noinline__ void phase_traverse(const DRenderParams* pp, uint32_t parity, uint32_t base, uint32_t count, WorkCounters* wc) {
     extern __shared__ uint4 lds_nodes[];
     const DRenderParams* P = uniform_ptr(pp);
@@ -1035,7 +1047,7 @@ __device__ __noinline__ void phase_traverse(const DRenderParams* pp, uint32_t pa
     w.base = uniform32(base);
     w.count = uniform32(count);
     WorkCounters local;
-    traverse_f32_wave<COUNT, LDS_NODES, false>(uniform_scene(P->sc), uniform_state(P->st[parity]), uniform_hits(P->hits), w,
+    traverse_f32_wave<COUNT, LDS_NODES, false, BATCH>(uniform_scene(P->sc), uniform_state(P->st[parity]), uniform_hits(P->hits), w,
                                                __longlong_as_double((long long)uniform64((unsigned long long)__double_as_longlong(P->tmin))),
                                                __longlong_as_double((long long)uniform64((unsigned long long)__double_as_longlong(P->tmax0))), uniform_p(P->ctl), local);
     if (COUNT) {
@@ -1054,7 +1066,7 @@ __device__ __noinline__ uint32_t phase_shade(const DRenderParams* pp, uint32_t p
                       uniform_state(P->st[parity ^ 1u]), uniform64(P->seed), uniform_p(P->accum));
 }
 
-template <bool COUNT, bool LDS_NODES>
+template <bool COUNT, bool LDS_NODES, bool BATCH>
 __global__ __launch_bounds__(RTX_PERSISTENT_BLOCK, RTX_PERSISTENT_WAVES) void k_render_persistent(const DRenderParams* P) {
     extern __shared__ uint4 lds_nodes[];
     if (LDS_NODES) {
@@ -1111,7 +1123,7 @@ __global__ __launch_bounds__(RTX_PERSISTENT_BLOCK, RTX_PERSISTENT_WAVES) void k_
         if (count == 0u) break;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         PP(pp_gen);
-        phase_traverse<COUNT, LDS_NODES>(P, parity, base, count, &wc);
+        phase_traverse<COUNT, LDS_NODES, BATCH>(P, parity, base, count, &wc);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         PP(pp_trav);
         n_rays += count;
@@ -1239,16 +1251,22 @@ void launch_traverse_f32(const DScene& sc, const DState& rays, const DHits& hits
         if (!once) {
             once = true;
             int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_traverse_f32<false, true>, TRAVERSE_LDS_BLOCK, lds);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_traverse_f32<false, true, false>, TRAVERSE_LDS_BLOCK, lds);
             std::fprintf(stderr, "OCCUPANCY k_traverse_f32<false,true>: %d blocks of %d threads per CU with %zu B LDS; grid %u\n", nb, TRAVERSE_LDS_BLOCK, lds, g.x);
         }
 #endif
-        if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, true>), g, b, lds, s, sc, rays, hits, pool, tmin, tmax, ctl, surf);
-        else hipLaunchKernelGGL((k_traverse_f32<false, true>), g, b, lds, s, sc, rays, hits, pool, tmin, tmax, ctl, surf);
+        const bool batch = sc.batch_undecided != 0u;
+        if (count_work && batch) hipLaunchKernelGGL((k_traverse_f32<true, true, true>), g, b, lds, s, sc, rays, hits, pool, tmin, tmax, ctl, surf);
+        else if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, true, false>), g, b, lds, s, sc, rays, hits, pool, tmin, tmax, ctl, surf);
+        else if (batch) hipLaunchKernelGGL((k_traverse_f32<false, true, true>), g, b, lds, s, sc, rays, hits, pool, tmin, tmax, ctl, surf);
+        else hipLaunchKernelGGL((k_traverse_f32<false, true, false>), g, b, lds, s, sc, rays, hits, pool, tmin, tmax, ctl, surf);
     } else {
         dim3 g(grid_for_pool(pool.n_sub)), b(BLOCK);
-        if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, false>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
-        else hipLaunchKernelGGL((k_traverse_f32<false, false>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
+        const bool batch = sc.batch_undecided != 0u;
+        if (count_work && batch) hipLaunchKernelGGL((k_traverse_f32<true, false, true>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
+        else if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, false, false>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
+        else if (batch) hipLaunchKernelGGL((k_traverse_f32<false, false, true>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
+        else hipLaunchKernelGGL((k_traverse_f32<false, false, false>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
     }
 }
 void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const DPool& pool, const DState& nxt,
@@ -1263,8 +1281,8 @@ size_t persistent_lds_bytes(const DScene& sc, uint32_t lds_mode) {
 uint32_t persistent_waves_per_cu(const DScene& sc, uint32_t lds_mode) {
     int nb = 0;
     const size_t lds = persistent_lds_bytes(sc, lds_mode);
-    hipError_t e = lds_mode ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, true>, RTX_PERSISTENT_BLOCK, lds)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, false>, RTX_PERSISTENT_BLOCK, lds);
+    hipError_t e = lds_mode ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, true, false>, RTX_PERSISTENT_BLOCK, lds)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, false, false>, RTX_PERSISTENT_BLOCK, lds);
     if (e != hipSuccess || nb < 1) nb = 1;
     return (uint32_t)nb * (RTX_PERSISTENT_BLOCK / 64);   // waves
 }
@@ -1273,12 +1291,17 @@ void launch_render_persistent(const DRenderParams* params, const DRenderParams& 
     const uint32_t block_waves = RTX_PERSISTENT_BLOCK / 64;
     dim3 g((host_params.n_sub + block_waves - 1) / block_waves), b(RTX_PERSISTENT_BLOCK);
     const size_t lds = persistent_lds_bytes(host_params.sc, lds_mode);
+    const bool batch = host_params.sc.batch_undecided != 0u;
     if (lds_mode) {
-        if (count_work) hipLaunchKernelGGL((k_render_persistent<true, true>), g, b, lds, s, params);
-        else hipLaunchKernelGGL((k_render_persistent<false, true>), g, b, lds, s, params);
+        if (count_work && batch) hipLaunchKernelGGL((k_render_persistent<true, true, true>), g, b, lds, s, params);
+        else if (count_work) hipLaunchKernelGGL((k_render_persistent<true, true, false>), g, b, lds, s, params);
+        else if (batch) hipLaunchKernelGGL((k_render_persistent<false, true, true>), g, b, lds, s, params);
+        else hipLaunchKernelGGL((k_render_persistent<false, true, false>), g, b, lds, s, params);
     } else {
-        if (count_work) hipLaunchKernelGGL((k_render_persistent<true, false>), g, b, 0, s, params);
-        else hipLaunchKernelGGL((k_render_persistent<false, false>), g, b, 0, s, params);
+        if (count_work && batch) hipLaunchKernelGGL((k_render_persistent<true, false, true>), g, b, 0, s, params);
+        else if (count_work) hipLaunchKernelGGL((k_render_persistent<true, false, false>), g, b, 0, s, params);
+        else if (batch) hipLaunchKernelGGL((k_render_persistent<false, false, true>), g, b, 0, s, params);
+        else hipLaunchKernelGGL((k_render_persistent<false, false, false>), g, b, 0, s, params);
     }
 }
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s) {

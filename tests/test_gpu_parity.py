@@ -139,6 +139,31 @@ def test_trace_closest_live_oracle(rt, oracle, built, name):
         d = rng.normal(size=org.shape) * rng.choice([1e-3, 1.0, 50.0], size=(len(org), 1))
 
 
+@pytest.mark.parametrize("batch", ["0", "1"], ids=["f64_boxes_in_loop", "f64_boxes_batched"])
+@pytest.mark.parametrize("name", ["cornell_box", "cover_spheres", "quads"])
+def test_undecided_boxes_in_loop_and_batched(rt, oracle, name, batch, monkeypatch):
+    """The box tests the f32 tier leaves open are resolved inside the walk's loop or for all waiting lanes together
+    (chosen per scene, here forced both ways): same hits, same distances, same number of box and surface tests."""
+    monkeypatch.setenv("RTX_BATCH_F64_BOXES", batch)
+    surfaces, cam = S.EXAMPLES[name]()
+    dev, orc = rt.Scene(rt.HostBVH(surfaces)), oracle.Scene(surfaces)
+    icam = rt.camera_initialize(dict(cam, image_width=min(cam["image_width"], 480)))
+    org, d = rt.primary_rays(icam, 3, 1)
+    rng = np.random.default_rng(5)
+    for bounce in range(3):
+        ids, t, st = dev.trace_closest(org, d, flags=rt.FLAG_COUNT_WORK)
+        wid, wt, ctr = orc.trace_closest(org, d)
+        assert np.array_equal(ids, wid) and np.array_equal(bits(t), bits(wt)), f"bounce {bounce}"
+        assert [st.node_visits, st.sphere_tests, st.planar_tests] == [ctr.node_visits, ctr.sphere_tests, ctr.planar_tests]
+        if name == "cornell_box":
+            assert st.box_fallbacks > 0.02 * st.node_visits   # this scene does exercise the f64 tiers
+        hit = ids != NONE
+        if not hit.any():
+            break
+        org = org[hit] + d[hit] * t[hit, None]
+        d = rng.normal(size=org.shape)
+
+
 def test_trace_closest_interval_and_ties(rt, oracle):
     lam = S.lambertian((1, 1, 1))
     surf = S.pack([S.quad((0, 0, 0), (1, 0, 0), (0, 1, 0), lam), S.quad((0, 0, 0), (1, 0, 0), (0, 1, 0), lam),
