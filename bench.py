@@ -25,6 +25,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver supports dmabuf IPC only: without this RCCL cannot share buffers between the ranks of a node
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 WIDTH, SPP, SEED, SCENE_SEED = 1920, 500, 0xC0FFEE, 0xC0FFEE
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (spec)
