@@ -9,8 +9,9 @@
  * Pinning: the reference cannot be compiled in this environment (no Rust
  * toolchain), so the restatement is pinned by the reference's own fixtures:
  *   - the five BVH-builder unit tests in src/bvh/mod.rs:191-479 (restated in
- *     tests/test_oracle_builder.py), and
- *   - images/hello_triangle_10k.png (tests/golden/).
+ *     tests/test_builder_reference_cases.py), and
+ *   - images/hello_triangle_10k.png and images/cornell_box_20k.png (copied as
+ *     data into tests/golden/), compared with converged renders.
  * Ray/box, ray/primitive, traversal and scatter arithmetic have no reference
  * test: for those the oracle is "parity unpinned" beyond the converged image.
  *
