@@ -159,3 +159,19 @@ def test_example_program_lists_the_examples():
     out = subprocess.run([exe, "--list"], capture_output=True, text=True, check=True).stdout.split()
     assert out == list(S.EXAMPLES)
     assert subprocess.run([exe, "nope"], capture_output=True).returncode == 1
+
+
+def test_rust_bindings_declare_the_whole_abi():
+    """bindings/rust/rtx-sys mirrors include/rtx.h: every function, and the struct fields in the header's order
+    (the crate cannot be compiled here; this keeps its text in step with the header)."""
+    header = open(os.path.join(ROOT, "include", "rtx.h")).read()
+    rust = open(os.path.join(ROOT, "bindings", "rust", "rtx-sys", "src", "lib.rs")).read()
+    for name in declared_functions("rtx.h"):
+        assert re.search(r"pub fn %s\s*\(" % name, rust), f"{name} missing from rtx-sys"
+    for struct in ("rtx_scene_desc", "rtx_camera", "rtx_stats", "rtx_build_stats"):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        c_fields = re.findall(r"(\w+)(?:\[\d+\])?\s*;", body)
+        r_body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, rust, re.S).group(1)
+        r_fields = re.findall(r"pub (\w+)\s*:", r_body)
+        assert c_fields == r_fields, (struct, c_fields, r_fields)
