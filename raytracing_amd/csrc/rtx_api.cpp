@@ -322,6 +322,10 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     // Many box tests of such a scene are left to the f64 tiers: the walk then collects those lanes and resolves
     // them together instead of one by one inside its loop (RTX_BATCH_F64_BOXES=0/1 overrides the choice).
     sc->d.batch_undecided = env_u32("RTX_BATCH_F64_BOXES", (uint64_t)thin_nodes * 20u >= n ? 1u : 0u, true);
+    // Waiting for more lanes before the surface tests run pays where those tests are the larger part of the walk:
+    // scenes of quads and triangles (57 flop a test, and their tripled boxes are hit often).
+    sc->d.pend_at = env_u32("RTX_PEND_AT", planars.size() > spheres.size() ? 32u : 16u);
+    if (sc->d.pend_at > 64u) sc->d.pend_at = 64u;
     sc->d.nodes32 = sc->nodes32.p;
     sc->d.boxes64 = sc->boxes64.p;
     sc->d.n_spheres = n_spheres;
