@@ -51,7 +51,9 @@ def main():
         build_s = time.perf_counter() - t0
         bst = bvh.build_stats
         icam = rt.camera_initialize(cam)
+        t0 = time.perf_counter()
         scene = rt.Scene(bvh)
+        scene_s = time.perf_counter() - t0
         spp_nominal = icam.samples_per_pixel
         spp = spp_run or spp_nominal
         acc = torch.zeros(icam.image_height, icam.image_width, 3, dtype=torch.float64, device=dev)
@@ -69,7 +71,7 @@ def main():
         print(json.dumps({
             "config": name, "image": f"{icam.image_width}x{icam.image_height}", "spp_nominal": spp_nominal, "spp_run": spp,
             "surfaces": int(len(surfaces)), "bvh_nodes": bvh.n_nodes, "bvh_build_call_s": round(build_s, 3),
-            "bvh_build_device_ms": round(bst.ms_sort + bst.ms_levels, 3), "bvh_levels": bst.levels,
+            "bvh_build_device_ms": round(bst.ms_sort + bst.ms_levels, 3), "bvh_levels": bst.levels, "scene_create_s": round(scene_s, 3),
             "render_s": round(dt, 4), "render_s_at_nominal_spp": round(dt * spp_nominal / spp, 3),
             "paths": st.paths, "rays": st.rays, "rays_per_path": round(st.rays / st.paths, 3),
             "mrays_per_s": round(st.rays / dt / 1e6, 1), "rounds": st.iterations,
