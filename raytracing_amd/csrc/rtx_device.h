@@ -476,7 +476,7 @@ __device__ __forceinline__ bool box_hit_f32(const float p[6], const RayF32& r, b
     const float T = fmaf(M, 12.2f * 0x1.0p-24f, r.K);
     const float m = fminf(fminf(hi - r.tmin32, r.tmax32 - lo), hi - lo);
     hit = m > T;
-    return hit || m < -T;
+    return fabsf(m) > T;   // T >= 0 (M >= 0: -mn or mx is; K >= 0), so this is m > T || m < -T in one comparison
 }
 
 // ---------------------------------------------------------------- primitive tests

@@ -631,20 +631,24 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
                                      __uint_as_float(n0.w), __uint_as_float(n1.x), __uint_as_float(n1.y)};
             bool hit;
             bool decided = box_hit_f32(planes, rf, hit);
+            const bool is_leaf = n1.w != NONE;
+            // The lanes that start waiting in this step are counted from the comparisons' own masks (the ballot of a
+            // combined flag costs two vector instructions per step): f32 says hit (that implies decided) on a leaf ...
+            uint32_t n_new = (uint32_t)__popcll(ballot64(hit) & ballot64(is_leaf));
+            if (batch_undecided) n_new += (uint32_t)__popcll(ballot64(true) & ~ballot64(decided));   // ... or undecided
             if (!decided && !batch_undecided) {   // few such tests in this scene: the exact box, f64 filter, then the division form, here
                 const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> 5));
                 const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
                 if (COUNT) ++c_fallback;
                 hit = tier2_box(q0, q1, q2, o, d, tmin, tmax, scene_filter);
-                decided = true;
+                decided = true;   // (a leaf found here waits uncounted: counting inside this branch would make the count per-lane)
             }
-            const bool is_leaf = n1.w != NONE;
             const bool found = decided && hit && is_leaf;
             if (decided) node = (hit && !is_leaf) ? node + 32u : n1.z;   // links are byte offsets; a leaf's successor is its miss link as well
             leaf = found ? n1.w : leaf;
             pending = found;
             undecided = !decided;
-            n_pending += (uint32_t)__popcll(ballot64(found || !decided));
+            n_pending += n_new;
             searching = decided && !found && node < end;
 #ifdef RTX_PROFILE_PHASES
             ++pt_iters;
