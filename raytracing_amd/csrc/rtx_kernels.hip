@@ -645,7 +645,7 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
             }
             const bool found = decided && hit && is_leaf;
             if (decided) node = (hit && !is_leaf) ? node + 32u : n1.z;   // links are byte offsets; a leaf's successor is its miss link as well
-            leaf = found ? n1.w : leaf;
+            leaf = n1.w;   // only read once the lane waits on this leaf; a lane that walks on overwrites it
             pending = found;
             undecided = !decided;
             n_pending += n_new;
