@@ -422,8 +422,11 @@ __device__ __forceinline__ bool filter_ray_ok(V3 o, V3 d, double tmin, double tm
 // of the ray, max/min over the axes move lo and hi by at most
 //     E = 4.05u (M + OI) + 1e-30
 // (the absolute term covers planes and products below the f32 normal range).
-// Let s1 = hi - tmin32, s2 = tmax32 - lo, s3 = hi - lo in f32 and m their
-// minimum.  Rounding tmin, tmax to f32 and the subtractions cost at most
+// Let s1 = hi - tmin32, s2 = tmax32 - lo, s3 = hi - lo and
+// m = RN32(min(hi, tmax32) - max(lo, tmin32)) = RN32(min(s1, s2, s3, tmax32 - tmin32));
+// the fourth term is never negative (tmin <= tmax), so it cannot make m
+// negative and only makes "true" harder to prove for intervals shorter than T.
+// Rounding tmin, tmax to f32 and the subtraction cost at most
 // 2^-22 max(tmin, tmax) more, so with M' = max(M, tg), tg = tmax32 if finite
 // else tmin32, and
 //     T = 12.2u M' + (8.1u OI + 2e-30)   >=   2E + 2^-22 tg (1 + small),
@@ -458,7 +461,7 @@ __device__ __forceinline__ void rayf32_init(RayF32& r, V3 o, V3 d, double tmin, 
         oi_max = fmaxf(oi_max, ao);
     }
     const float t = (float)tmin;
-    ok = ok && t >= 1e-30f && t <= 1e15f;
+    ok = ok && t >= 1e-30f && t <= 1e15f && tmin <= tmax;   // box_hit_f32 relies on tmin <= tmax
     r.tmin32 = t;
     r.K = ok ? oi_max * (8.1f * 0x1.0p-24f) + 2e-30f : __builtin_inff();
     rayf32_set_tmax(r, tmax);
@@ -474,7 +477,7 @@ __device__ __forceinline__ bool box_hit_f32(const float p[6], const RayF32& r, b
     const float mn = fminf(fminf(nx, ny), nz), mx = fmaxf(fmaxf(fx, fy), fz);
     const float M = fmaxf(fmaxf(-mn, mx), r.tg);
     const float T = fmaf(M, 12.2f * 0x1.0p-24f, r.K);
-    const float m = fminf(fminf(hi - r.tmin32, r.tmax32 - lo), hi - lo);
+    const float m = fminf(hi, r.tmax32) - fmaxf(lo, r.tmin32);   // = min(s1, s2, s3, tmax32 - tmin32), one subtraction
     hit = m > T;
     return fabsf(m) > T;   // T >= 0 (M >= 0: -mn or mx is; K >= 0), so this is m > T || m < -T in one comparison
 }
