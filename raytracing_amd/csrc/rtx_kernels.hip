@@ -681,17 +681,25 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
             bool ph;
             if (kind == 0u) {
                 if (COUNT) ++c_sph;
-                const double2* spp = (LDS_NODES && w.lds_surfaces) ? reinterpret_cast<const double2*>(w.lds_spheres + 2u * slot)
-                                                                 : reinterpret_cast<const double2*>(sc.spheres + slot);
-                const double2 sa = spp[0], sb = spp[1];
+                double2 sa, sb;
+                if (LDS_NODES && w.lds_surfaces) {   // wave-uniform: a branch, not a per-lane choice between two address spaces
+                    typedef __attribute__((address_space(3))) const double* lds_ptr;   // keeps the two paths from being merged into one flat load
+                    const lds_ptr spp = (lds_ptr)reinterpret_cast<const double*>(w.lds_spheres + 2u * slot);
+                    sa = make_double2(spp[0], spp[1]);
+                    sb = make_double2(spp[2], spp[3]);
+                } else {
+                    const double2* spp = reinterpret_cast<const double2*>(sc.spheres + slot);
+                    sa = spp[0];
+                    sb = spp[1];
+                }
                 DSphere sp;
                 sp.c[0] = sa.x; sp.c[1] = sa.y; sp.c[2] = sb.x; sp.r = sb.y;
                 ph = sphere_t(sp, o, d, tmin, tmax, t);
             } else {
                 if (COUNT) ++c_pln;
                 double al, be;
-                const DPlanar* gp = (LDS_NODES && w.lds_surfaces) ? reinterpret_cast<const DPlanar*>(w.lds_planars + 8u * slot) : sc.planars + slot;
-                ph = planar_t(*gp, kind, o, d, tmin, tmax, t, al, be);
+                if (LDS_NODES && w.lds_surfaces) ph = planar_t(*reinterpret_cast<const DPlanar*>(w.lds_planars + 8u * slot), kind, o, d, tmin, tmax, t, al, be);
+                else ph = planar_t(sc.planars[slot], kind, o, d, tmin, tmax, t, al, be);
             }
             // `if let Some(nearest) = acc && hit.t > nearest.t { keep } else { replace }`
             if (ph && !(best_leaf != NONE && t > tmax)) {
