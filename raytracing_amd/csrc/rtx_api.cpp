@@ -326,6 +326,11 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     // scenes of quads and triangles (57 flop a test, and their tripled boxes are hit often).
     sc->d.pend_at = env_u32("RTX_PEND_AT", planars.size() > spheres.size() ? 32u : 16u);
     if (sc->d.pend_at > 64u) sc->d.pend_at = 64u;
+    // Idle lanes take their next rays once 32 lanes are idle; once 16 are where the whole scene sits in LDS and the surface tests
+    // dominate (Cornell box +8 %, quads +4 %; the headline scene loses 2 % with 16, a 10^6-triangle tree in global memory 5 %).
+    const size_t scene_bytes = (size_t)n * sizeof(DNode32) + spheres.size() * sizeof(DSphere) + planars.size() * sizeof(DPlanar);
+    sc->d.refill_at = env_u32("RTX_REFILL_AT", planars.size() > spheres.size() && scene_bytes <= 32u * 1024u ? 16u : 32u);
+    if (sc->d.refill_at > 64u) sc->d.refill_at = 64u;
     sc->d.nodes32 = sc->nodes32.p;
     sc->d.boxes64 = sc->boxes64.p;
     sc->d.n_spheres = n_spheres;

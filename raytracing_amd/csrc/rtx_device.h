@@ -97,6 +97,7 @@ struct DScene {
     uint32_t filter_ok;   // every box coordinate is finite and small enough for the filtered box test
     uint32_t batch_undecided;   // box tests the f32 tier leaves open are resolved for many lanes at once, after the node walk
     uint32_t pend_at;           // the walk runs the waiting lanes' surface tests once this many lanes wait
+    uint32_t refill_at;         // ... and gives idle lanes their next rays once this many lanes are idle
     const DNode32* nodes32;
     const DBox64* boxes64;
     uint32_t n_spheres, n_planars;

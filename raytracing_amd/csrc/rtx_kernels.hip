@@ -41,9 +41,6 @@ constexpr uint32_t MAX_BLOCK_WAVES = TRAVERSE_LDS_BLOCK / 64 > BLOCK / 64 ? TRAV
 #ifndef RTX_PERSISTENT_BLOCK
 #define RTX_PERSISTENT_BLOCK 256
 #endif
-#ifndef RTX_REFILL_AT
-#define RTX_REFILL_AT 32
-#endif
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 // 64-wide ballot straight from the condition mask (the generic __ballot first turns the flag into an integer)
@@ -546,7 +543,7 @@ template <bool COUNT, bool LDS_NODES, bool SHARED, bool BATCH>
 __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState& rays, const DHits& hits, const TraverseWork& w, double tmin,
                                                   double tmax0, DRenderCtl* ctl, WorkCounters& wc) {
     const uint32_t lane = lane_id();
-    constexpr uint32_t REFILL_AT = RTX_REFILL_AT;   // refill once this many lanes are idle
+    const uint32_t REFILL_AT = sc.refill_at;        // refill once this many lanes are idle (wave-uniform)
     const uint32_t PEND_AT = sc.pend_at;            // test surfaces once this many lanes stand on a leaf (wave-uniform)
     const uint32_t p_end = SHARED ? w.s_first[MAX_BLOCK_WAVES] : w.count;
     bool list_done = p_end == 0u;
@@ -1031,7 +1028,7 @@ __device__ __forceinline__ DScene uniform_scene(const DScene& s) {
     u.nodes = uniform_p(s.nodes); u.spheres = uniform_p(s.spheres); u.planars = uniform_p(s.planars);
     u.nodes32 = uniform_p(s.nodes32);
     u.boxes64 = uniform_p(s.boxes64); u.shade_recs = uniform_p(s.shade_recs); u.rec_user_id = uniform_p(s.rec_user_id);
-    u.n_nodes = uniform32(s.n_nodes); u.filter_ok = uniform32(s.filter_ok); u.batch_undecided = uniform32(s.batch_undecided); u.pend_at = uniform32(s.pend_at);
+    u.n_nodes = uniform32(s.n_nodes); u.filter_ok = uniform32(s.filter_ok); u.batch_undecided = uniform32(s.batch_undecided); u.pend_at = uniform32(s.pend_at); u.refill_at = uniform32(s.refill_at);
     u.n_spheres = uniform32(s.n_spheres); u.n_planars = uniform32(s.n_planars);
     return u;
 }
