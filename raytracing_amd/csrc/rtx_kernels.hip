@@ -43,6 +43,10 @@ constexpr uint32_t MAX_BLOCK_WAVES = TRAVERSE_LDS_BLOCK / 64 > BLOCK / 64 ? TRAV
 #endif
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+// Ray state and hit records stream through once per bounce: their loads are marked non-temporal, so the lines they bring do not
+// displace the surface and material tables (the frame +2 %; non-temporal stores cost it 6 %).
+template <class T> __device__ __forceinline__ T ld_stream(const T* p) { return __builtin_nontemporal_load(p); }
+template <class T, class U> __device__ __forceinline__ void st_stream(T* p, U v) { *p = (T)v; }
 // 64-wide ballot straight from the condition mask (the generic __ballot first turns the flag into an integer)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // readfirstlane as unsigned (the builtin returns int, which would sign-extend when widened) and for 64-bit values
@@ -269,13 +273,13 @@ __device__ __forceinline__ void generate_wave(const DCamera& cam, const DState& 
         start_path_wave(cam, seed, valid, pixel, sample, o, d, draw);
         if (!valid) continue;
         const uint32_t k = slot0 + i;
-        st.ox[k] = o.x; st.oy[k] = o.y; st.oz[k] = o.z;
-        st.dx[k] = d.x; st.dy[k] = d.y; st.dz[k] = d.z;
-        st.bx[k] = 1.0; st.by[k] = 1.0; st.bz[k] = 1.0;
-        st.pixel[k] = pixel;
-        st.sample[k] = sample;
-        st.draw[k] = draw;
-        st.depth[k] = 0u;
+        st_stream(&st.ox[k], o.x); st_stream(&st.oy[k], o.y); st_stream(&st.oz[k], o.z);
+        st_stream(&st.dx[k], d.x); st_stream(&st.dy[k], d.y); st_stream(&st.dz[k], d.z);
+        st_stream(&st.bx[k], 1.0); st_stream(&st.by[k], 1.0); st_stream(&st.bz[k], 1.0);
+        st_stream(&st.pixel[k], pixel);
+        st_stream(&st.sample[k], sample);
+        st_stream(&st.draw[k], draw);
+        st_stream(&st.depth[k], 0u);
     }
 }
 
@@ -593,8 +597,8 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
                     mine = (w.first_pool + j) * w.sub_capacity + (p - w.s_first[j]);
                 }
                 idx = mine;
-                o = v3(rays.ox[mine], rays.oy[mine], rays.oz[mine]);
-                d = v3(rays.dx[mine], rays.dy[mine], rays.dz[mine]);
+                o = v3(ld_stream(&rays.ox[mine]), ld_stream(&rays.oy[mine]), ld_stream(&rays.oz[mine]));
+                d = v3(ld_stream(&rays.dx[mine]), ld_stream(&rays.dy[mine]), ld_stream(&rays.dz[mine]));
                 tmax = tmax0;
                 best_leaf = NONE;
                 node = 0;
@@ -710,8 +714,8 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
         PT(pt_p2);
         // ---- retire rays that have run out of tree
         if (idx != NONE && node >= end) {
-            hits.prim[idx] = best_leaf;
-            hits.t[idx] = tmax;
+            st_stream(&hits.prim[idx], best_leaf);
+            st_stream(&hits.t[idx], tmax);
             idx = NONE;
         }
         PT(pt_retire);
@@ -850,15 +854,15 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
         double t = 0.0;
         V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
         if (off < count) {
-            handle = hits.prim[i];
-            t = hits.t[i];
-            o = v3(cur.ox[i], cur.oy[i], cur.oz[i]);
-            d = v3(cur.dx[i], cur.dy[i], cur.dz[i]);
-            beta = v3(cur.bx[i], cur.by[i], cur.bz[i]);
-            pixel = cur.pixel[i];
-            sample = cur.sample[i];
-            draw0 = cur.draw[i];
-            depth0 = cur.depth[i];
+            handle = ld_stream(&hits.prim[i]);
+            t = ld_stream(&hits.t[i]);
+            o = v3(ld_stream(&cur.ox[i]), ld_stream(&cur.oy[i]), ld_stream(&cur.oz[i]));
+            d = v3(ld_stream(&cur.dx[i]), ld_stream(&cur.dy[i]), ld_stream(&cur.dz[i]));
+            beta = v3(ld_stream(&cur.bx[i]), ld_stream(&cur.by[i]), ld_stream(&cur.bz[i]));
+            pixel = ld_stream(&cur.pixel[i]);
+            sample = ld_stream(&cur.sample[i]);
+            draw0 = ld_stream(&cur.draw[i]);
+            depth0 = ld_stream(&cur.depth[i]);
         }
         // Material::scatter (material.rs:20-33) is one sampling event: it starts on a block boundary of the path's
         // stream.  Lambertian and Metal both start with Vector3::random_unit() (material.rs:62, :86), run here for the wave.
@@ -962,13 +966,13 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
         const unsigned long long amask = ballot64(alive);
         if (alive) {
             const uint32_t k = base + n_out + rank_below(amask, lane);
-            nxt.ox[k] = p.x; nxt.oy[k] = p.y; nxt.oz[k] = p.z;
-            nxt.dx[k] = nd.x; nxt.dy[k] = nd.y; nxt.dz[k] = nd.z;
-            nxt.bx[k] = beta.x; nxt.by[k] = beta.y; nxt.bz[k] = beta.z;
-            nxt.pixel[k] = pixel;
-            nxt.sample[k] = sample;
-            nxt.draw[k] = draw;
-            nxt.depth[k] = depth;
+            st_stream(&nxt.ox[k], p.x); st_stream(&nxt.oy[k], p.y); st_stream(&nxt.oz[k], p.z);
+            st_stream(&nxt.dx[k], nd.x); st_stream(&nxt.dy[k], nd.y); st_stream(&nxt.dz[k], nd.z);
+            st_stream(&nxt.bx[k], beta.x); st_stream(&nxt.by[k], beta.y); st_stream(&nxt.bz[k], beta.z);
+            st_stream(&nxt.pixel[k], pixel);
+            st_stream(&nxt.sample[k], sample);
+            st_stream(&nxt.draw[k], draw);
+            st_stream(&nxt.depth[k], depth);
         }
         n_out += (uint32_t)__popcll(amask);
     }
