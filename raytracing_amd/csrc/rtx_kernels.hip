@@ -820,12 +820,12 @@ __device__ __forceinline__ double reflectance(double cos_theta, double refractio
 // Sphere u,v (geometry.rs:236-240), from the world-space point as the reference has it.  Out of line: no
 // example scene puts UVGradient on a sphere, and inlined the acos/atan2 polynomials keep two dozen
 // registers of coefficients alive through the whole shade loop.
-__device__ __noinline__ void sphere_uv(double px, double py, double pz, double& alpha, double& beta_uv) {
+// (The pair is returned by value: reference arguments of an out-of-line function live in scratch memory.)
+__device__ __noinline__ double2 sphere_uv(double px, double py, double pz) {
     const double PI = 3.14159265358979323846264338327950288;
     const double theta = acos(-py);
     const double phi = atan2(-pz, px) + PI;
-    alpha = phi / (2.0 * PI);
-    beta_uv = theta / PI;
+    return make_double2(phi / (2.0 * PI), theta / PI);
 }
 
 // One step of ray_color (src/camera.rs:184-208) in its iterative form:
@@ -891,7 +891,11 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
                 double alpha = 0.0, beta_uv = 0.0;
                 if (!planar) {
                     outward = (p - rec_a) * r1.y;   // (p - center) / radius
-                    if (mkind == 4u) sphere_uv(p.x, p.y, p.z, alpha, beta_uv);   // u,v only feed UVGradient
+                    if (mkind == 4u) {   // u,v only feed UVGradient
+                        const double2 uv = sphere_uv(p.x, p.y, p.z);
+                        alpha = uv.x;
+                        beta_uv = uv.y;
+                    }
                 } else {
                     outward = rec_a;
                     if (mkind == 4u) {
@@ -997,12 +1001,23 @@ __global__ __launch_bounds__(BLOCK, RTX_SHADE_WAVES) void k_shade(DScene sc, DCa
 // The only shared words are the path counter (one returning atomic per wave
 // and round) and the accumulation buffer.  A sub-pool is written and read by
 // its own wave only; workgroup-scope fences order the phases.
-// The three phases are separate functions, not inlined: each gets its own
-// register allocation (the kernel's register count is the largest of them, not
-// their sum), and a call per phase per round costs nothing against the phase.
+// The three phases of the single-launch kernel.  They are inlined into it: as separate functions each saved and restored
+// 28 callee-saved vector registers per call (7 KB of scratch traffic per wave and call, 8 % of the frame's memory traffic;
+// inlined the frame is 4 % faster).  -DRTX_CALL_PHASES builds them as calls again.
+#ifdef RTX_CALL_PHASES
+#define RTX_PHASE_INLINE __noinline__
+#else
+#define RTX_PHASE_INLINE __forceinline__
+#endif
 __device__ __forceinline__ const DRenderParams* uniform_ptr(const DRenderParams* p) {
     typedef __attribute__((address_space(1))) const DRenderParams* global_ptr;
-    return (const DRenderParams*)(global_ptr)uniform64((unsigned long long)p);
+    unsigned long long v = uniform64((unsigned long long)p);
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    // A phase reads its tables through a pointer the compiler cannot see through: otherwise the table pointers of all three
+    // phases are loaded once before the round loop and stay in (or are spilled from) scalar registers for the whole launch.
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    v = ((unsigned long long)hi << 32) | lo;
+    return (const DRenderParams*)(global_ptr)v;
 }
 // Copies of the parameter record's tables with every pointer in scalar registers.  Loaded through the
 // (uniform) parameter pointer they would otherwise sit in vector registers, two per pointer, and spill.
@@ -1036,7 +1051,7 @@ __device__ __forceinline__ DScene uniform_scene(const DScene& s) {
     u.n_spheres = uniform32(s.n_spheres); u.n_planars = uniform32(s.n_planars);
     return u;
 }
-__device__ __noinline__ void phase_generate(const DRenderParams* pp, uint32_t parity, uint32_t slot0, unsigned long long first, uint32_t got) {
+__device__ RTX_PHASE_INLINE void phase_generate(const DRenderParams* pp, uint32_t parity, uint32_t slot0, unsigned long long first, uint32_t got) {
     const DRenderParams* P = uniform_ptr(pp);
     parity = uniform32(parity);
     slot0 = uniform32(slot0);
@@ -1045,7 +1060,7 @@ __device__ __noinline__ void phase_generate(const DRenderParams* pp, uint32_t pa
     generate_wave(P->cam, uniform_state(P->st[parity]), slot0, first, got, uniform64(P->seed), uniform32(P->spp_begin));
 }
 template <bool COUNT, bool LDS_NODES, bool BATCH>
-__device__ __noinline__ void phase_traverse(const DRenderParams* pp, uint32_t parity, uint32_t base, uint32_t count, WorkCounters* wc) {
+__device__ RTX_PHASE_INLINE void phase_traverse(const DRenderParams* pp, uint32_t parity, uint32_t base, uint32_t count, WorkCounters* wc) {
     extern __shared__ uint4 lds_nodes[];
     const DRenderParams* P = uniform_ptr(pp);
     parity = uniform32(parity);
@@ -1067,7 +1082,7 @@ __device__ __noinline__ void phase_traverse(const DRenderParams* pp, uint32_t pa
         wc->fallbacks += local.fallbacks;
     }
 }
-__device__ __noinline__ uint32_t phase_shade(const DRenderParams* pp, uint32_t parity, uint32_t base, uint32_t count) {
+__device__ RTX_PHASE_INLINE uint32_t phase_shade(const DRenderParams* pp, uint32_t parity, uint32_t base, uint32_t count) {
     const DRenderParams* P = uniform_ptr(pp);
     parity = uniform32(parity);
     base = uniform32(base);
@@ -1099,8 +1114,8 @@ __global__ __launch_bounds__(RTX_PERSISTENT_BLOCK, RTX_PERSISTENT_WAVES) void k_
     const uint32_t lane = lane_id();
     const uint32_t cap = uniform32(P->cap);
     const uint32_t base = wave * cap;
-    DRenderCtl* const ctl = P->ctl;
-    const unsigned long long total = ctl->total_paths;
+    DRenderCtl* const ctl = uniform_p(P->ctl);
+    const unsigned long long total = uniform64(ctl->total_paths);
     WorkCounters wc;
     unsigned long long n_rays = 0;
     uint32_t rounds = 0, count = 0, parity = 0;
