@@ -154,6 +154,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:   # set up the communicator and its channels for this buffer before anything is timed (also with --warmup 0)
+        reduce_accum(acc, world)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()
