@@ -842,27 +842,44 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
                                                uint32_t count, const DState& nxt, uint64_t seed, double* accum) {
     const uint32_t lane = lane_id();
     uint32_t n_out = 0;   // survivors written so far (wave-uniform)
+    // What the sampling at the top of a row needs (hit, pixel, sample, draw count) is read one row ahead, so a row starts
+    // computing at once while the rest of its state and the record of its surface are on their way.
+    uint32_t handle_n = NONE, pixel_n = 0, sample_n = 0, draw_n = 0;
+    if (lane < count) {
+        handle_n = ld_stream(&hits.prim[base + lane]);
+        pixel_n = ld_stream(&cur.pixel[base + lane]);
+        sample_n = ld_stream(&cur.sample[base + lane]);
+        draw_n = ld_stream(&cur.draw[base + lane]);
+    }
     for (uint32_t t0 = 0; t0 < count; t0 += 64u) {
         const uint32_t off = t0 + lane;
         const uint32_t i = base + off;
         bool alive = false;
         V3 p = v3(0, 0, 0), nd = v3(0, 0, 0), beta = v3(0, 0, 0);
-        uint32_t pixel = 0, sample = 0, draw = 0, depth = 0;
-        // every load that does not depend on another is issued here, up front;
-        // the surface record is the only dependent round trip
-        uint32_t handle = NONE, draw0 = 0, depth0 = 0;
+        uint32_t draw = 0, depth = 0;
+        const uint32_t handle = handle_n, pixel = pixel_n, sample = sample_n, draw0 = draw_n;
+        uint32_t depth0 = 0;
         double t = 0.0;
         V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
         if (off < count) {
-            handle = ld_stream(&hits.prim[i]);
             t = ld_stream(&hits.t[i]);
             o = v3(ld_stream(&cur.ox[i]), ld_stream(&cur.oy[i]), ld_stream(&cur.oz[i]));
             d = v3(ld_stream(&cur.dx[i]), ld_stream(&cur.dy[i]), ld_stream(&cur.dz[i]));
             beta = v3(ld_stream(&cur.bx[i]), ld_stream(&cur.by[i]), ld_stream(&cur.bz[i]));
-            pixel = ld_stream(&cur.pixel[i]);
-            sample = ld_stream(&cur.sample[i]);
-            draw0 = ld_stream(&cur.draw[i]);
             depth0 = ld_stream(&cur.depth[i]);
+        }
+        handle_n = NONE;
+        if (off + 64u < count) {
+            handle_n = ld_stream(&hits.prim[i + 64u]);
+            pixel_n = ld_stream(&cur.pixel[i + 64u]);
+            sample_n = ld_stream(&cur.sample[i + 64u]);
+            draw_n = ld_stream(&cur.draw[i + 64u]);
+        }
+        // the record of the surface that was hit: requested as soon as the hit is known, so that it arrives during the sampling below
+        double2 r0 = make_double2(0, 0), r1 = r0, r2 = r0, r3 = r0;
+        if (off < count && handle != NONE) {
+            const double2* rp = reinterpret_cast<const double2*>(sc.shade_recs + (code_geom(handle) != 0u ? sc.n_spheres + code_slot(handle) : code_slot(handle)));
+            r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
         }
         // Material::scatter (material.rs:20-33) is one sampling event: it starts on a block boundary of the path's
         // stream.  Lambertian and Metal both start with Vector3::random_unit() (material.rs:62, :86), run here for the wave.
@@ -880,8 +897,6 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
             } else {
                 const uint32_t mkind = code_mat(handle), slot = code_slot(handle);
                 const bool planar = code_geom(handle) != 0u;
-                const double2* rp = reinterpret_cast<const double2*>(sc.shade_recs + (planar ? sc.n_spheres + slot : slot));
-                const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
                 const V3 rec_a = v3(r0.x, r0.y, r1.x);
                 const V3 rgb = v3(r2.x, r2.y, r3.x);
                 const double param = r3.y;
