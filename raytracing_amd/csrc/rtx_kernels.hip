@@ -221,17 +221,21 @@ __device__ __forceinline__ void start_path_wave(const DCamera& cam, uint64_t see
 }
 
 // Path g of a render call is sample (spp_begin + g / npix) of the pixel that
-// position g % npix of a scrambled pixel order names.  The order keeps runs of
-// 64 consecutive pixels together (a wave starts 64 neighbouring primary rays,
-// which walk the tree together) but sends consecutive runs to far-apart parts
-// of the image: run r of the order is run (r * RUN_STEP) mod n_runs of the
-// image.  A sub-pool therefore holds rays from all over the image, and the
-// cost of a sub-pool varies little from one to the next; with runs in image
-// order, the waves whose sub-pools hold an expensive region of the image take
-// several times longer than the rest.  The pixels after the last whole run
-// keep their place.  Which pixel a path index names does not change the
-// image: every (pixel, sample) is still rendered exactly once.
+// position g % npix of the pixel order names.  The single launch takes pixels in
+// image order: the rays of a sub-pool then come from neighbouring pixels, stay
+// together through the compactions and walk the tree together (+2.6 % on the
+// headline frame against the scrambled order); its waves do not wait for each
+// other, so a sub-pool over an expensive part of the image just takes fewer
+// paths.  The round loop (SCRAMBLE) keeps runs of 64 consecutive pixels
+// together but sends consecutive runs to far-apart parts of the image: run r
+// of the order is run (r * RUN_STEP) mod n_runs of the image.  There a launch
+// ends when its slowest wave does, and with runs in image order the waves
+// whose sub-pools hold an expensive region take several times longer than the
+// rest.  The pixels after the last whole run keep their place.  Which pixel a
+// path index names does not change the image: every (pixel, sample) is still
+// rendered exactly once.
 constexpr unsigned long long RUN_STEP = 1000003ull;   // prime; a bijection on runs unless n_runs is a multiple of it
+template <bool SCRAMBLE>
 __device__ __forceinline__ void split_path_index(unsigned long long g, unsigned long long npix, uint32_t& pixel, uint32_t& sample_off) {
     unsigned long long q;
     if (g < (1ull << 52)) {
@@ -247,7 +251,7 @@ __device__ __forceinline__ void split_path_index(unsigned long long g, unsigned 
     const uint32_t pos = (uint32_t)(g - q * npix);
     const uint32_t n_runs = (uint32_t)(npix >> 6);
     uint32_t run = pos >> 6;
-    if (run < n_runs && n_runs % RUN_STEP != 0ull) {
+    if (SCRAMBLE && run < n_runs && n_runs % RUN_STEP != 0ull) {
         const unsigned long long prod = (unsigned long long)run * (RUN_STEP % n_runs);   // < 2^32 * 2^32
         // prod mod n_runs by one f64 division (prod < 2^52 for every image of at most 2^32 pixels)
         unsigned long long qq = (unsigned long long)((double)prod / (double)n_runs);
@@ -259,6 +263,7 @@ __device__ __forceinline__ void split_path_index(unsigned long long g, unsigned 
 }
 
 // The wave starts paths first .. first + n_new - 1 in slots slot0 .. of `st`.
+template <bool SCRAMBLE>
 __device__ __forceinline__ void generate_wave(const DCamera& cam, const DState& st, uint32_t slot0, unsigned long long first, uint32_t n_new,
                                               uint64_t seed, uint32_t spp_begin) {
     const unsigned long long npix = (unsigned long long)cam.image_width * cam.image_height;
@@ -266,7 +271,7 @@ __device__ __forceinline__ void generate_wave(const DCamera& cam, const DState& 
         const uint32_t i = i0 + lane_id();
         const bool valid = i < n_new;
         uint32_t pixel, sample_off;
-        split_path_index(first + (valid ? i : 0u), npix, pixel, sample_off);
+        split_path_index<SCRAMBLE>(first + (valid ? i : 0u), npix, pixel, sample_off);
         const uint32_t sample = spp_begin + sample_off;
         V3 o, d;
         uint32_t draw;
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DCamera cam, DState st, DRen
         ctl->live_total = (uint32_t)(surv_total + started);
         ctl->rays += surv_total + started;
     }
-    generate_wave(cam, st, w * cap + my_surv, my_first, my_new, seed, spp_begin);
+    generate_wave<true>(cam, st, w * cap + my_surv, my_first, my_new, seed, spp_begin);
 }
 
 // Primary rays only, for the parity API (rays laid out [n][3]).
@@ -1072,7 +1077,7 @@ __device__ RTX_PHASE_INLINE void phase_generate(const DRenderParams* pp, uint32_
     slot0 = uniform32(slot0);
     got = uniform32(got);
     first = uniform64(first);
-    generate_wave(P->cam, uniform_state(P->st[parity]), slot0, first, got, uniform64(P->seed), uniform32(P->spp_begin));
+    generate_wave<false>(P->cam, uniform_state(P->st[parity]), slot0, first, got, uniform64(P->seed), uniform32(P->spp_begin));
 }
 template <bool COUNT, bool LDS_NODES, bool BATCH>
 __device__ RTX_PHASE_INLINE void phase_traverse(const DRenderParams* pp, uint32_t parity, uint32_t base, uint32_t count, WorkCounters* wc) {
