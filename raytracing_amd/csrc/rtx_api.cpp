@@ -526,7 +526,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         PathPool* pp = sc->lane(0);
         const uint32_t mode = lds_mode_for(sc, flags);
         const uint32_t waves = sc->n_cus * persistent_waves_per_cu(sc->d, mode);   // exactly what is resident at once
-        const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 23);   // ~1600 slots per wave: a wave's round ends with a drain, so long rounds pay
+        const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 22);   // ~800 slots per wave: a round ends with a drain, so long rounds pay, but state that stays in the last-level cache pays too
         const uint64_t need = total < want ? total : want;
         uint32_t n_sub;
         uint64_t per_sub;
