@@ -1107,8 +1107,11 @@ __device__ RTX_PHASE_INLINE uint32_t phase_shade(const DRenderParams* pp, uint32
     parity = uniform32(parity);
     base = uniform32(base);
     count = uniform32(count);
-    return shade_wave(uniform_scene(P->sc), P->cam, uniform_state(P->st[parity]), uniform_hits(P->hits), base, count,
-                      uniform_state(P->st[parity ^ 1u]), uniform64(P->seed), uniform_p(P->accum));
+    // The survivors are compacted in place: a row's survivors go to slots at or before the row's own, which no later row reads
+    // (the row header read one row ahead lies behind them as well).  One buffer instead of two halves the state's footprint in the
+    // last-level cache and the scalar registers that hold table pointers (+1.5 % on the frame).
+    const DState st = uniform_state(P->st[parity]);
+    return shade_wave(uniform_scene(P->sc), P->cam, st, uniform_hits(P->hits), base, count, st, uniform64(P->seed), uniform_p(P->accum));
 }
 
 template <bool COUNT, bool LDS_NODES, bool BATCH>
@@ -1176,7 +1179,6 @@ __global__ __launch_bounds__(RTX_PERSISTENT_BLOCK, RTX_PERSISTENT_WAVES) void k_
         count = uniform32(phase_shade(P, parity, base, count));
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         PP(pp_shade);
-        parity ^= 1u;
     }
 #ifdef RTX_PROFILE_PHASES
     if (lane == 0) {
