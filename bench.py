@@ -59,7 +59,11 @@ def measured_valu_issue(kernel):
         c = recs[name]
         xcd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0           # summed over the 8 XCDs
         return {
-            "busy_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (xcd_cycles * 1024.0), 3),   # 4 cycles per instruction, 1024 SIMDs
+            # SQ_ACTIVE_INST_VALU counts 4 cycles per instruction: the share of time a SIMD has a vector instruction in flight,
+            # not the load of its arithmetic pipe (which retires a 32-bit instruction in 2 cycles, an f64 one in 4)
+            "busy_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (xcd_cycles * 1024.0), 3),   # 1024 SIMDs
+            "valu_insts_per_cycle_per_simd": round(c["SQ_INSTS_VALU"] / 1024.0 / xcd_cycles, 3),
+            "valu_insts_per_cycle_per_simd_ceiling": {"b32": 0.45, "f64": 0.25, "source": "profiles/r01_valu_rate.txt (tools/ubench/valu_rate.hip)"},
             "lanes_active_frac": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 3),
             "source": "profiles/r01_pmc_summary.json (SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE, SQ_THREAD_CYCLES_VALU)",
         }
