@@ -131,7 +131,7 @@ struct DCamera {   // InitializedCamera, src/camera.rs:28-43
 // The path pool is split into one private sub-pool per wave of the (fixed)
 // launch grid: wave w of every kernel works on slots
 // [w * sub_capacity, w * sub_capacity + counts[w]).  A wave compacts its own
-// survivors into its own sub-pool of the other buffer, in order, so no two
+// survivors into its own sub-pool (of the other buffer in the round loop, in place in the single launch), in order, so no two
 // waves ever write the same counter or reserve slots from a shared one: the
 // round loop has no atomics besides the radiance accumulation.  (A returning
 // atomic on a single address sustains fewer than 100 operations per

@@ -841,7 +841,8 @@ __device__ __noinline__ double2 sphere_uv(double px, double py, double pz) {
 // only on surfaces that do not scatter this is the same product of
 // attenuations, associated from the other end.
 // The wave walks `count` rays from slot `base` on, 64 at a time, and appends
-// the survivors, in order, from slot `base` of the other buffer on.  Returns
+// the survivors, in order, from slot `base` of `nxt` on (the other buffer, or the
+// same one: a row's survivors never go behind the row's own slots).  Returns
 // the number of survivors.
 __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, uint32_t base,
                                                uint32_t count, const DState& nxt, uint64_t seed, double* accum) {
