@@ -524,7 +524,13 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     // single-precision box tier; calls that ask for another tier, or scenes outside its range, take the round loop below.
     if (sc->f32_ok && !(flags & (RTX_FLAG_EXACT_DIVIDE | RTX_FLAG_F64_FILTER | RTX_FLAG_TIME_KERNELS)) && env_u32("RTX_PERSISTENT", 1, true) != 0u) {
         PathPool* pp = sc->lane(0);
-        const uint32_t mode = lds_mode_for(sc, flags);
+        uint32_t mode = lds_mode_for(sc, flags);
+        if (mode == 1u) {
+            // The tree fits in LDS five times per CU but tree + surface tables do not: one 1024-thread block per CU then holds both
+            // once for sixteen waves (RTX_LDS_WIDE_BYTES: largest such scene, 0 = never; above 64 KB a launch would need its limit raised).
+            const uint32_t wide_limit = env_u32("RTX_LDS_WIDE_BYTES", 64u * 1024u, true);
+            if (persistent_lds_bytes(sc->d, 3u) <= (wide_limit < 64u * 1024u ? wide_limit : 64u * 1024u)) mode = 3u;
+        }
         const uint32_t waves = sc->n_cus * persistent_waves_per_cu(sc->d, mode);   // exactly what is resident at once
         const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 22);   // ~800 slots per wave: a round ends with a drain, so long rounds pay, but state that stays in the last-level cache pays too
         const uint64_t need = total < want ? total : want;
@@ -551,7 +557,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         P.n_sub = n_sub;
         P.cap = (uint32_t)per_sub;
         P.spp_begin = spp_begin;
-        P.lds_surfaces = mode == 2u ? 1u : 0u;
+        P.lds_surfaces = mode >= 2u ? 1u : 0u;
         HIP_TRY(hipMemcpyAsync(pp->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
 #ifdef RTX_PROFILE_PHASES
         HIP_TRY(hipMemsetAsync(pp->ctl.p + 1, 0, 7 * sizeof(DRenderCtl), s));
