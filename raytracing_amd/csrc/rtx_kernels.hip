@@ -1349,17 +1349,17 @@ void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const
                   uint32_t* counts_out, uint64_t seed, double* accum, hipStream_t s) {
     hipLaunchKernelGGL(k_shade, dim3(grid_for_pool(pool.n_sub)), dim3(BLOCK), 0, s, sc, cam, cur, hits, pool, nxt, counts_out, seed, accum);
 }
-// lds_mode: 0 tree in global memory; 1 tree in LDS; 2 tree and surface tables in LDS; 3 the same in the WIDE form of the kernel
+// lds_mode: 0 tree in global memory; 1 tree in LDS; 2 tree and surface tables in LDS; 3 and 4: modes 2 and 1 in the WIDE form of the kernel
 size_t persistent_lds_bytes(const DScene& sc, uint32_t lds_mode) {
     size_t lds = lds_mode ? (size_t)sc.n_nodes * sizeof(DNode32) : 0;
-    if (lds_mode >= 2u) lds += (size_t)sc.n_spheres * sizeof(DSphere) + (size_t)sc.n_planars * sizeof(DPlanar);
+    if (lds_mode == 2u || lds_mode == 3u) lds += (size_t)sc.n_spheres * sizeof(DSphere) + (size_t)sc.n_planars * sizeof(DPlanar);
     return lds;
 }
 uint32_t persistent_waves_per_cu(const DScene& sc, uint32_t lds_mode) {
     int nb = 0;
     const size_t lds = persistent_lds_bytes(sc, lds_mode);
-    const uint32_t block = lds_mode == 3u ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK;
-    hipError_t e = lds_mode == 3u ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, true, false, true>, block, lds)
+    const uint32_t block = lds_mode >= 3u ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK;
+    hipError_t e = lds_mode >= 3u ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, true, false, true>, block, lds)
                    : lds_mode  ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, true, false>, block, lds)
                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, false, false>, block, lds);
     if (e != hipSuccess || nb < 1) nb = 1;
@@ -1367,12 +1367,12 @@ uint32_t persistent_waves_per_cu(const DScene& sc, uint32_t lds_mode) {
 }
 // `params` is device memory; host_params is the same record on the host (for the grid and LDS size).
 void launch_render_persistent(const DRenderParams* params, const DRenderParams& host_params, bool count_work, uint32_t lds_mode, hipStream_t s) {
-    const uint32_t block = lds_mode == 3u ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK;
+    const uint32_t block = lds_mode >= 3u ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK;
     const uint32_t block_waves = block / 64;
     dim3 g((host_params.n_sub + block_waves - 1) / block_waves), b(block);
     const size_t lds = persistent_lds_bytes(host_params.sc, lds_mode);
     const bool batch = host_params.sc.batch_undecided != 0u;
-    if (lds_mode == 3u) {
+    if (lds_mode >= 3u) {
         if (count_work && batch) hipLaunchKernelGGL((k_render_persistent<true, true, true, true>), g, b, lds, s, params);
         else if (count_work) hipLaunchKernelGGL((k_render_persistent<true, true, false, true>), g, b, lds, s, params);
         else if (batch) hipLaunchKernelGGL((k_render_persistent<false, true, true, true>), g, b, lds, s, params);

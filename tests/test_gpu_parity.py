@@ -270,6 +270,26 @@ def test_radiance_matches_recursive_ray_color(rt, oracle, name):
     assert np.allclose(got, want, rtol=1e-12, atol=1e-300)
 
 
+@pytest.mark.parametrize("n,kind,wide", [(1500, "spheres", "1"), (2300, "spheres", "1"), (900, "triangles", "1"), (1500, "spheres", "0")])
+def test_mid_size_scenes_in_the_one_block_per_cu_form(rt, oracle, n, kind, wide, monkeypatch):
+    """Trees too large for five LDS copies per CU but small enough for one (1500 spheres: tree and spheres in LDS;
+    2300 spheres and 900 triangles: the tree alone), and the same scene from global memory: same paths, bit for bit."""
+    import torch
+
+    monkeypatch.setenv("RTX_LDS_WIDE_BYTES", str(150 * 1024) if wide == "1" else "0")
+    surfaces, cam = S.synthetic_soup(n=n, kind=kind, seed=7, image_width=192, samples_per_pixel=1)
+    cam = dict(cam, max_depth=6)
+    dev = rt.Scene(rt.HostBVH(surfaces))
+    orc = oracle.Scene(surfaces)
+    icam, ocam = rt.camera_initialize(cam), oracle.camera_initialize(cam)
+    acc = torch.zeros(icam.image_height, icam.image_width, 3, dtype=torch.float64, device="cuda")
+    st = dev.render_accumulate(icam, 11, 0, 1, acc.data_ptr(), torch.cuda.current_stream().cuda_stream, rt.FLAG_COUNT_WORK)
+    want, ctr = orc.render(ocam, 11, 0, 1, iterative=True)
+    assert [st.rays, st.paths, st.node_visits, st.sphere_tests, st.planar_tests] == \
+           [ctr.rays, ctr.paths, ctr.node_visits, ctr.sphere_tests, ctr.planar_tests]
+    assert np.array_equal(bits(acc.cpu().numpy() + 0.0), bits(want + 0.0))
+
+
 def test_depth_limit_and_pool_smaller_than_job(rt, oracle, monkeypatch):
     surfaces, cam = S.cornell_box()
     for max_depth in (1, 2, 7):
