@@ -43,7 +43,8 @@ def measured_traffic(kernel):
         with open(TRAFFIC_FILE) as fh:
             recs = json.load(fh)["kernels"]
         # template instances are listed separately ("k_traverse_f32<false, true>"): the render path's is the one launched most
-        name = max((k for k in recs if k.split("<")[0] == kernel), key=lambda k: recs[k]["launches"])
+        # the work-counting instance ("<true, ...") is not the one that is timed
+        name = max((k for k in recs if k.split("<")[0] == kernel), key=lambda k: (not k.startswith(kernel + "<true"), recs[k]["launches"]))
         return recs[name]["hbm_bytes_per_launch"], "profiles/hbm_traffic.json: " + recs[name].get("source", "")
     except (OSError, KeyError, ValueError):
         return None, None
@@ -55,7 +56,7 @@ def measured_valu_issue(kernel):
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as fh:
             recs = json.load(fh)["kernels"]
-        name = max((k for k in recs if k.split("<")[0] == kernel), key=lambda k: recs[k].get("SQ_WAVES", 0))
+        name = max((k for k in recs if k.split("<")[0] == kernel), key=lambda k: (not k.startswith(kernel + "<true"), recs[k].get("SQ_WAVES", 0)))
         c = recs[name]
         xcd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0           # summed over the 8 XCDs
         return {
