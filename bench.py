@@ -242,9 +242,9 @@ def main():
                 "nodes_per_ray": round(nv, 3),
                 "sphere_tests_per_ray": round(ns, 3),
                 "box_tests_left_to_f64_tiers": cnt.box_fallbacks / max(cnt.node_visits, 1),
-                "note": "one persistent launch renders the frame; the tree (31 KB of f32 node records) sits in LDS and the sphere table "
-                        "in L1/L2, so most algorithmic bytes are served on-chip and only the ray state, hit records and accumulation "
-                        "reach HBM (traffic): the kernel is bound by VALU issue and divergence; see valu_f64",
+                "note": "one persistent launch renders the frame; the tree (31 KB of f32 node records) and the sphere table (15 KB) sit in LDS, "
+                        "so most algorithmic bytes are served on-chip and only the ray state, hit records and accumulation "
+                        "reach HBM (traffic): the kernel is bound by memory latency, VALU issue and divergence; see valu_issue and valu_f64",
                 "valu_f64": {"achieved_tflops": round(achieved_tf, 3), "peak_tflops": FP64_VECTOR_PEAK_TF,
                              "frac": round(achieved_tf / FP64_VECTOR_PEAK_TF, 4), "flops_per_ray": round(flops_per_ray, 1)},
                 "valu_issue": measured_valu_issue(kernel),
