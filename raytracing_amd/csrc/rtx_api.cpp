@@ -525,14 +525,18 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     if (sc->f32_ok && !(flags & (RTX_FLAG_EXACT_DIVIDE | RTX_FLAG_F64_FILTER | RTX_FLAG_TIME_KERNELS)) && env_u32("RTX_PERSISTENT", 1, true) != 0u) {
         PathPool* pp = sc->lane(0);
         uint32_t mode = lds_mode_for(sc, flags);
+        bool lds_recs = false;   // the shade records next to the surface tables, where there is room
         if (mode <= 1u && !(flags & RTX_FLAG_NO_LDS)) {
             // What does not fit in LDS five times per CU may fit once: one 1024-thread block per CU then holds the tree, and the surface
             // tables if there is room, for sixteen waves (RTX_LDS_WIDE_BYTES: the most LDS such a block may take, 0 = never).
             const size_t wide_limit = env_u32("RTX_LDS_WIDE_BYTES", 150u * 1024u, true);
-            if (persistent_lds_bytes(sc->d, 3u) <= wide_limit) mode = 3u;
-            else if (mode == 0u && persistent_lds_bytes(sc->d, 4u) <= wide_limit) mode = 4u;
+            if (persistent_lds_bytes(sc->d, 3u, false) <= wide_limit) mode = 3u;
+            else if (mode == 0u && persistent_lds_bytes(sc->d, 4u, false) <= wide_limit) mode = 4u;
+            if (mode == 3u) lds_recs = persistent_lds_bytes(sc->d, 3u, true) <= wide_limit;
         }
-        const uint32_t waves = sc->n_cus * persistent_waves_per_cu(sc->d, mode);   // exactly what is resident at once
+        if (mode == 2u) lds_recs = persistent_lds_bytes(sc->d, 2u, true) <= env_u32("RTX_LDS_SCENE_BYTES", 32u * 1024u);
+        if (env_u32("RTX_LDS_RECS", 1, true) == 0u) lds_recs = false;
+        const uint32_t waves = sc->n_cus * persistent_waves_per_cu(sc->d, mode, lds_recs);   // exactly what is resident at once
         const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 22);   // ~800 slots per wave: a round ends with a drain, so long rounds pay, but state that stays in the last-level cache pays too
         const uint64_t need = total < want ? total : want;
         uint32_t n_sub;
@@ -559,6 +563,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         P.cap = (uint32_t)per_sub;
         P.spp_begin = spp_begin;
         P.lds_surfaces = (mode == 2u || mode == 3u) ? 1u : 0u;
+        P.lds_recs = lds_recs ? 1u : 0u;
         HIP_TRY(hipMemcpyAsync(pp->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
 #ifdef RTX_PROFILE_PHASES
         HIP_TRY(hipMemsetAsync(pp->ctl.p + 1, 0, 7 * sizeof(DRenderCtl), s));

@@ -171,6 +171,7 @@ struct DRenderParams {
     unsigned long long seed;
     double tmin, tmax0;
     uint32_t n_sub, cap, spp_begin, lds_surfaces;
+    uint32_t lds_recs, pad_[3];   // the shade records are in LDS as well (behind the surface tables)
 };
 
 // ---------------------------------------------------------------- Vector3 (src/vector.rs)

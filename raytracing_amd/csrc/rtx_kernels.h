@@ -19,8 +19,8 @@ void launch_traverse_f32(const DScene& sc, const DState& rays, const DHits& hits
 void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, const DPool& pool, const DState& nxt,
                   uint32_t* counts_out, uint64_t seed, double* accum, hipStream_t s);
 // The whole sample loop as one launch of persistent waves (f32 box tier only).  `params` is device memory.
-size_t persistent_lds_bytes(const DScene& sc, uint32_t lds_mode);
-uint32_t persistent_waves_per_cu(const DScene& sc, uint32_t lds_mode);
+size_t persistent_lds_bytes(const DScene& sc, uint32_t lds_mode, bool recs);
+uint32_t persistent_waves_per_cu(const DScene& sc, uint32_t lds_mode, bool recs);
 void launch_render_persistent(const DRenderParams* params, const DRenderParams& host_params, bool count_work, uint32_t lds_mode, hipStream_t s);
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s);
 void launch_quantize(const double* in, uint64_t n, uint8_t* out, hipStream_t s);

@@ -846,7 +846,7 @@ __device__ __noinline__ double2 sphere_uv(double px, double py, double pz) {
 // the number of survivors.
 template <bool DEEP>
 __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& cam, const DState& cur, const DHits& hits, uint32_t base,
-                                               uint32_t count, const DState& nxt, uint64_t seed, double* accum) {
+                                               uint32_t count, const DState& nxt, uint64_t seed, double* accum, const uint4* lds_recs = nullptr) {
     const uint32_t lane = lane_id();
     uint32_t n_out = 0;   // survivors written so far (wave-uniform)
     // What the sampling at the top of a row needs (hit, pixel, sample, draw count) is read one row ahead, so a row starts
@@ -906,8 +906,15 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
         // the record of the surface that was hit: requested as soon as the hit is known, so that it arrives during the sampling below
         double2 r0 = make_double2(0, 0), r1 = r0, r2 = r0, r3 = r0;
         if (off < count && handle != NONE) {
-            const double2* rp = reinterpret_cast<const double2*>(sc.shade_recs + (code_geom(handle) != 0u ? sc.n_spheres + code_slot(handle) : code_slot(handle)));
-            r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
+            const uint32_t rec = code_geom(handle) != 0u ? sc.n_spheres + code_slot(handle) : code_slot(handle);
+            if (lds_recs) {   // wave-uniform
+                typedef __attribute__((address_space(3))) const double* lds_ptr;
+                const lds_ptr rp = (lds_ptr)reinterpret_cast<const double*>(lds_recs + 4u * rec);
+                r0 = make_double2(rp[0], rp[1]); r1 = make_double2(rp[2], rp[3]); r2 = make_double2(rp[4], rp[5]); r3 = make_double2(rp[6], rp[7]);
+            } else {
+                const double2* rp = reinterpret_cast<const double2*>(sc.shade_recs + rec);
+                r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
+            }
         }
         // Material::scatter (material.rs:20-33) is one sampling event: it starts on a block boundary of the path's
         // stream.  Lambertian and Metal both start with Vector3::random_unit() (material.rs:62, :86), run here for the wave.
@@ -1135,7 +1142,9 @@ __device__ RTX_PHASE_INLINE uint32_t phase_shade(const DRenderParams* pp, uint32
     // (the row header read one row ahead lies behind them as well).  One buffer instead of two halves the state's footprint in the
     // last-level cache and the scalar registers that hold table pointers (+1.5 % on the frame).
     const DState st = uniform_state(P->st[parity]);
-    return shade_wave<DEEP>(uniform_scene(P->sc), P->cam, st, uniform_hits(P->hits), base, count, st, uniform64(P->seed), uniform_p(P->accum));
+    extern __shared__ uint4 lds_nodes[];
+    const uint4* lds_recs = uniform32(P->lds_recs) ? lds_nodes + 2u * P->sc.n_nodes + 2u * P->sc.n_spheres + 8u * P->sc.n_planars : nullptr;
+    return shade_wave<DEEP>(uniform_scene(P->sc), P->cam, st, uniform_hits(P->hits), base, count, st, uniform64(P->seed), uniform_p(P->accum), lds_recs);
 }
 
 // WIDE: one block of 1024 threads per CU (four waves per SIMD instead of five, 128 registers each instead of 96) so that one LDS
@@ -1157,6 +1166,11 @@ __global__ __launch_bounds__(WIDE ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK, WIDE ? 4 
             uint4* dst_p = dst_s + 2u * sc.n_spheres;
             const uint4* src_p = reinterpret_cast<const uint4*>(sc.planars);
             for (uint32_t i = threadIdx.x; i < 8u * sc.n_planars; i += blockDim.x) dst_p[i] = src_p[i];
+            if (P->lds_recs) {
+                uint4* dst_r = dst_p + 8u * sc.n_planars;
+                const uint4* src_r = reinterpret_cast<const uint4*>(sc.shade_recs);
+                for (uint32_t i = threadIdx.x; i < 4u * (sc.n_spheres + sc.n_planars); i += blockDim.x) dst_r[i] = src_r[i];
+            }
         }
         __syncthreads();
     }
@@ -1350,14 +1364,17 @@ void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const
     hipLaunchKernelGGL(k_shade, dim3(grid_for_pool(pool.n_sub)), dim3(BLOCK), 0, s, sc, cam, cur, hits, pool, nxt, counts_out, seed, accum);
 }
 // lds_mode: 0 tree in global memory; 1 tree in LDS; 2 tree and surface tables in LDS; 3 and 4: modes 2 and 1 in the WIDE form of the kernel
-size_t persistent_lds_bytes(const DScene& sc, uint32_t lds_mode) {
+size_t persistent_lds_bytes(const DScene& sc, uint32_t lds_mode, bool recs) {
     size_t lds = lds_mode ? (size_t)sc.n_nodes * sizeof(DNode32) : 0;
-    if (lds_mode == 2u || lds_mode == 3u) lds += (size_t)sc.n_spheres * sizeof(DSphere) + (size_t)sc.n_planars * sizeof(DPlanar);
+    if (lds_mode == 2u || lds_mode == 3u) {
+        lds += (size_t)sc.n_spheres * sizeof(DSphere) + (size_t)sc.n_planars * sizeof(DPlanar);
+        if (recs) lds += ((size_t)sc.n_spheres + sc.n_planars) * sizeof(DShadeRec);
+    }
     return lds;
 }
-uint32_t persistent_waves_per_cu(const DScene& sc, uint32_t lds_mode) {
+uint32_t persistent_waves_per_cu(const DScene& sc, uint32_t lds_mode, bool recs) {
     int nb = 0;
-    const size_t lds = persistent_lds_bytes(sc, lds_mode);
+    const size_t lds = persistent_lds_bytes(sc, lds_mode, recs);
     const uint32_t block = lds_mode >= 3u ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK;
     hipError_t e = lds_mode >= 3u ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, true, false, true>, block, lds)
                    : lds_mode  ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, true, false>, block, lds)
@@ -1370,7 +1387,7 @@ void launch_render_persistent(const DRenderParams* params, const DRenderParams& 
     const uint32_t block = lds_mode >= 3u ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK;
     const uint32_t block_waves = block / 64;
     dim3 g((host_params.n_sub + block_waves - 1) / block_waves), b(block);
-    const size_t lds = persistent_lds_bytes(host_params.sc, lds_mode);
+    const size_t lds = persistent_lds_bytes(host_params.sc, lds_mode, host_params.lds_recs != 0u);
     const bool batch = host_params.sc.batch_undecided != 0u;
     if (lds_mode >= 3u) {
         if (count_work && batch) hipLaunchKernelGGL((k_render_persistent<true, true, true, true>), g, b, lds, s, params);
