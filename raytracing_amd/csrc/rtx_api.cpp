@@ -323,13 +323,15 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     // them together instead of one by one inside its loop (RTX_BATCH_F64_BOXES=0/1 overrides the choice).
     sc->d.batch_undecided = env_u32("RTX_BATCH_F64_BOXES", (uint64_t)thin_nodes * 20u >= n ? 1u : 0u, true);
     // Waiting for more lanes before the surface tests run pays where those tests are the larger part of the walk:
-    // scenes of quads and triangles (57 flop a test, and their tripled boxes are hit often).
-    sc->d.pend_at = env_u32("RTX_PEND_AT", planars.size() > spheres.size() ? 32u : 16u);
+    // scenes of quads and triangles (57 flop a test, and their tripled boxes are hit often); most where the whole scene sits in LDS
+    // (Cornell box: 40 lanes +1.8 % over 32; a 10^6-triangle tree in global memory loses 4.5 % with 40).
+    const size_t scene_bytes = (size_t)n * sizeof(DNode32) + spheres.size() * sizeof(DSphere) + planars.size() * sizeof(DPlanar);
+    const bool planar_scene = planars.size() > spheres.size(), small_scene = scene_bytes <= 32u * 1024u;
+    sc->d.pend_at = env_u32("RTX_PEND_AT", planar_scene ? (small_scene ? 40u : 32u) : 16u);
     if (sc->d.pend_at > 64u) sc->d.pend_at = 64u;
     // Idle lanes take their next rays once 32 lanes are idle; once 16 are where the whole scene sits in LDS and the surface tests
     // dominate (Cornell box +8 %, quads +4 %; the headline scene loses 2 % with 16, a 10^6-triangle tree in global memory 5 %).
-    const size_t scene_bytes = (size_t)n * sizeof(DNode32) + spheres.size() * sizeof(DSphere) + planars.size() * sizeof(DPlanar);
-    sc->d.refill_at = env_u32("RTX_REFILL_AT", planars.size() > spheres.size() && scene_bytes <= 32u * 1024u ? 16u : 32u);
+    sc->d.refill_at = env_u32("RTX_REFILL_AT", planar_scene && small_scene ? 16u : 32u);
     if (sc->d.refill_at > 64u) sc->d.refill_at = 64u;
     sc->d.nodes32 = sc->nodes32.p;
     sc->d.boxes64 = sc->boxes64.p;
