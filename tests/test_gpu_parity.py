@@ -390,7 +390,8 @@ def test_cornell_box_golden_png(rt, oracle):
     b = oracle.ppm_quantize(rt.run(surfaces, cam, seed=2)).astype(float)
     floor = np.sqrt(((a - b) ** 2).mean()) / np.sqrt(2.0)   # noise of ONE render
     rmse = np.sqrt(((a - png) ** 2).mean())
-    assert rmse <= 1.25 * floor + 0.5, (rmse, floor)
+    print(f"cornell golden: rmse {rmse:.4f}, noise floor of one render {floor:.4f}, ratio {rmse / floor:.4f}")
+    assert rmse <= 1.25 * floor, (rmse, floor)
     assert abs(a.mean() - png.mean()) < 1.0                  # no brightness bias
 
 
