@@ -2,8 +2,7 @@
 //
 // Host-side responsibilities: validate and upload the flattened BVH, own the
 // path pool, drive the traverse/shade rounds, and report counters and times.
-#include "../../include/rtx.h"
-#include "rtx_kernels.h"
+#include "rtx_internal.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -24,39 +23,13 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                                      \
-    do {                                                                                                   \
-        hipError_t _e = (expr);                                                                            \
-        if (_e != hipSuccess) {                                                                            \
-            int code = (_e == hipErrorOutOfMemory) ? RTX_ERR_OOM : (_e == hipErrorNoDevice ? RTX_ERR_NO_DEVICE : RTX_ERR_HIP); \
-            return fail(code, std::string(#expr) + ": " + hipGetErrorString(_e));                         \
-        }                                                                                                  \
-    } while (0)
+}  // namespace
 
-template <class T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    ~DevBuf() { release(); }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-    }
-    hipError_t resize(size_t count) {
-        if (count <= n) return hipSuccess;
-        release();
-        hipError_t e = hipMalloc((void**)&p, (count ? count : 1) * sizeof(T));
-        if (e == hipSuccess) n = count;
-        return e;
-    }
-    DevBuf() = default;
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-};
+namespace rtx {
 
-// Sizes and counts: 0 is not a valid value and yields the default; switches pass zero_ok.
-uint32_t env_u32(const char* name, uint32_t dflt, bool zero_ok = false) {
+int api_fail(int code, const std::string& msg) { return fail(code, msg); }
+
+uint32_t env_u32(const char* name, uint32_t dflt, bool zero_ok) {
     const char* v = std::getenv(name);
     if (!v || !*v) return dflt;
     char* end = nullptr;
@@ -65,91 +38,103 @@ uint32_t env_u32(const char* name, uint32_t dflt, bool zero_ok = false) {
     return (uint32_t)x;
 }
 
-}  // namespace
+PathPool::~PathPool() {
+    for (hipEvent_t e : kernel_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_poll) if (e) (void)hipEventDestroy(e);
+    if (ev_done) (void)hipEventDestroy(ev_done);
+    if (h_poll) (void)hipHostFree(h_poll);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+int PathPool::ensure_host_side() {
+    if (!stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (hipEvent_t& e : ev_poll) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!ev_done) HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    if (!h_poll) HIP_TRY(hipHostMalloc((void**)&h_poll, 2 * sizeof(uint32_t), hipHostMallocDefault));
+    return RTX_OK;
+}
+int PathPool::ensure_counters(uint32_t n_sub) {
+    if (n_sub <= counters_n) return RTX_OK;
+    HIP_TRY(counters.resize(3 * (size_t)n_sub));
+    counters_n = n_sub;
+    return RTX_OK;
+}
+int PathPool::ensure_capacity(size_t n) {
+    HIP_TRY(ctl.resize(8));   // the records behind the first are scratch for instrumented debug builds
+    if (n <= capacity) return RTX_OK;
+    // Both new buffers are allocated before either old one is let go: if one allocation fails the pool is
+    // exactly as it was (RTX_ERR_OOM is recoverable), never half replaced with `capacity` describing freed memory.
+    // The old buffers are released first only when they are all that stands in the way (second attempt).
+    DevBuf<double> nf;
+    DevBuf<uint32_t> nu;
+    hipError_t e = nf.resize(19 * n);
+    if (e == hipSuccess) e = nu.resize(9 * n);
+    if (e == hipErrorOutOfMemory && capacity) {
+        (void)hipGetLastError();
+        nf.release();
+        nu.release();
+        buf_f64.release();
+        buf_u32.release();
+        capacity = 0;
+        state[0] = state[1] = DState{};
+        hits = DHits{};
+        e = nf.resize(19 * n);
+        if (e == hipSuccess) e = nu.resize(9 * n);
+    }
+    HIP_TRY(e);
+    buf_f64.swap(nf);
+    buf_u32.swap(nu);
+    double* f = buf_f64.p;
+    uint32_t* u = buf_u32.p;
+    for (int b = 0; b < 2; ++b) {
+        DState& st = state[b];
+        st.ox = f; st.oy = f + n; st.oz = f + 2 * n; st.dx = f + 3 * n; st.dy = f + 4 * n; st.dz = f + 5 * n;
+        st.bx = f + 6 * n; st.by = f + 7 * n; st.bz = f + 8 * n;
+        f += 9 * n;
+        st.pixel = u; st.sample = u + n; st.draw = u + 2 * n; st.depth = u + 3 * n;
+        u += 4 * n;
+    }
+    hits.t = f;
+    hits.prim = u;
+    capacity = n;
+    return RTX_OK;
+}
 
-// One lane of the render loop: a path pool (two ping-pong state buffers and
-// the hit records), its control block and per-sub-pool counters, and the
-// stream its rounds run on.  Lanes are independent; a render call runs
-// several of them side by side so that one lane's closest-hit kernel (bound
-// by VALU issue) overlaps another lane's shade kernel (bound by memory latency).
-struct PathPool {
-    size_t capacity = 0;
-    DevBuf<double> buf_f64;     // 2 x 9 state arrays + hit_t
-    DevBuf<uint32_t> buf_u32;   // 2 x 4 state arrays + hit_prim
-    DevBuf<DRenderCtl> ctl;
-    DevBuf<uint32_t> counters;  // per sub-pool: live, survivors[0], survivors[1]
-    uint32_t counters_n = 0;
-    DevBuf<DRenderParams> params;   // launch record of the single-launch render
-    DState state[2]{};
-    DHits hits{};
-    hipStream_t stream = nullptr;            // owned
-    hipEvent_t ev_poll[2] = {nullptr, nullptr}, ev_done = nullptr;
-    uint32_t* h_poll = nullptr;              // two pinned words the host polls for the end of the lane's work
-    std::vector<hipEvent_t> kernel_events;   // reused by RTX_FLAG_TIME_KERNELS, 3 per round
+}  // namespace rtx
 
-    ~PathPool() {
-        for (hipEvent_t e : kernel_events) (void)hipEventDestroy(e);
-        for (hipEvent_t e : ev_poll) if (e) (void)hipEventDestroy(e);
-        if (ev_done) (void)hipEventDestroy(ev_done);
-        if (h_poll) (void)hipHostFree(h_poll);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
-    int ensure_host_side() {
-        if (!stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        for (hipEvent_t& e : ev_poll) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        if (!ev_done) HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
-        if (!h_poll) HIP_TRY(hipHostMalloc((void**)&h_poll, 2 * sizeof(uint32_t), hipHostMallocDefault));
-        return RTX_OK;
-    }
-    int ensure_counters(uint32_t n_sub) {
-        if (n_sub <= counters_n) return RTX_OK;
-        HIP_TRY(counters.resize(3 * (size_t)n_sub));
-        counters_n = n_sub;
-        return RTX_OK;
-    }
-    int ensure_capacity(size_t n) {
-        HIP_TRY(ctl.resize(8));   // the records behind the first are scratch for instrumented debug builds
-        if (n <= capacity) return RTX_OK;
-        HIP_TRY(buf_f64.resize(19 * n));
-        HIP_TRY(buf_u32.resize(9 * n));
-        double* f = buf_f64.p;
-        uint32_t* u = buf_u32.p;
-        for (int b = 0; b < 2; ++b) {
-            DState& st = state[b];
-            st.ox = f; st.oy = f + n; st.oz = f + 2 * n; st.dx = f + 3 * n; st.dy = f + 4 * n; st.dz = f + 5 * n;
-            st.bx = f + 6 * n; st.by = f + 7 * n; st.bz = f + 8 * n;
-            f += 9 * n;
-            st.pixel = u; st.sample = u + n; st.draw = u + 2 * n; st.depth = u + 3 * n;
-            u += 4 * n;
-        }
-        hits.t = f;
-        hits.prim = u;
-        capacity = n;
-        return RTX_OK;
-    }
-};
+void rtx::pool_geometry(uint64_t need, uint32_t max_waves, uint32_t* n_sub, uint64_t* sub_capacity) {
+    uint64_t waves = (need + 63) / 64;
+    waves = (waves + 3) & ~3ull;
+    if (waves < 4) waves = 4;
+    if (waves > max_waves) waves = max_waves;
+    *n_sub = (uint32_t)waves;
+    *sub_capacity = (((need + waves - 1) / waves) + 63) & ~63ull;
+}
 
-struct rtx_scene {
-    int device = 0;
-    uint32_t n_cus = 256;
-    DScene d{};
-    DevBuf<DNode> nodes;
-    DevBuf<DSphere> spheres;
-    DevBuf<DPlanar> planars;
-    DevBuf<DNode32> nodes32;
-    DevBuf<DBox64> boxes64;
-    DevBuf<uint32_t> rec_user_id;
-    DevBuf<DShadeRec> shade_recs;
-    bool f32_ok = false;   // every box plane is small enough for the single-precision tier
-    // Lanes of the render loop, created on first use and kept.  Lane 0 also serves rtx_trace_closest.
-    std::vector<std::unique_ptr<PathPool>> lanes;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+// 0: tree in global memory; 1: f32 node records in LDS; 2: node records and surface tables in LDS
+static uint32_t lds_mode_for(const rtx_scene* sc, uint32_t flags) {
+    const uint32_t lds_limit = env_u32("RTX_LDS_SCENE_BYTES", 32u * 1024u);   // five blocks of the kernel per CU
+    const size_t tree = (size_t)sc->d.n_nodes * sizeof(DNode32);
+    const size_t surf = (size_t)sc->d.n_spheres * sizeof(DSphere) + (size_t)sc->d.n_planars * sizeof(DPlanar);
+    if ((flags & RTX_FLAG_NO_LDS) || tree > lds_limit) return 0u;
+    return tree + surf <= lds_limit ? 2u : 1u;
+}
 
-    PathPool* lane(size_t j) {
-        while (lanes.size() <= j) lanes.emplace_back(new PathPool());
-        return lanes[j].get();
+// Which closest-hit kernel a call uses: the reference's division form when the
+// caller asks for it, else the tiered test with the f32 records in LDS (small
+// trees), from global memory (large trees), or the f64-only filter (scenes
+// whose box planes are too large for f32, or on request).
+void rtx::run_traverse(const rtx_scene* sc, const DState& rays, const DHits& hits, const DPool& pool, double tmin, double tmax,
+                       uint32_t flags, DRenderCtl* ctl, hipStream_t s) {
+    const bool count_work = (flags & RTX_FLAG_COUNT_WORK) != 0;
+    if (flags & RTX_FLAG_EXACT_DIVIDE) {
+        launch_traverse(sc->d, rays, hits, pool, tmin, tmax, ctl, count_work, true, s);
+    } else if ((flags & RTX_FLAG_F64_FILTER) || !sc->f32_ok) {
+        launch_traverse(sc->d, rays, hits, pool, tmin, tmax, ctl, count_work, false, s);
+    } else {
+        const uint32_t mode = lds_mode_for(sc, flags);
+        launch_traverse_f32(sc->d, rays, hits, pool, tmin, tmax, ctl, count_work, mode, s);
     }
-};
+}
 
 extern "C" {
 
@@ -353,43 +338,6 @@ void rtx_scene_destroy(rtx_scene* sc) {
     delete sc;
 }
 
-// Splits `need` slots into one sub-pool per wave of the launch grid: at most
-// `max_waves` sub-pools (a multiple of the waves per block), each a multiple of 64 slots.
-static void pool_geometry(uint64_t need, uint32_t max_waves, uint32_t* n_sub, uint64_t* sub_capacity) {
-    uint64_t waves = (need + 63) / 64;
-    waves = (waves + 3) & ~3ull;
-    if (waves < 4) waves = 4;
-    if (waves > max_waves) waves = max_waves;
-    *n_sub = (uint32_t)waves;
-    *sub_capacity = (((need + waves - 1) / waves) + 63) & ~63ull;
-}
-
-// 0: tree in global memory; 1: f32 node records in LDS; 2: node records and surface tables in LDS
-static uint32_t lds_mode_for(const rtx_scene* sc, uint32_t flags) {
-    const uint32_t lds_limit = env_u32("RTX_LDS_SCENE_BYTES", 32u * 1024u);   // five blocks of the kernel per CU
-    const size_t tree = (size_t)sc->d.n_nodes * sizeof(DNode32);
-    const size_t surf = (size_t)sc->d.n_spheres * sizeof(DSphere) + (size_t)sc->d.n_planars * sizeof(DPlanar);
-    if ((flags & RTX_FLAG_NO_LDS) || tree > lds_limit) return 0u;
-    return tree + surf <= lds_limit ? 2u : 1u;
-}
-
-// Which closest-hit kernel a call uses: the reference's division form when the
-// caller asks for it, else the tiered test with the f32 records in LDS (small
-// trees), from global memory (large trees), or the f64-only filter (scenes
-// whose box planes are too large for f32, or on request).
-static void run_traverse(rtx_scene* sc, PathPool* pp, const DState& rays, const DPool& pool, double tmin, double tmax, uint32_t flags,
-                         hipStream_t s) {
-    const bool count_work = (flags & RTX_FLAG_COUNT_WORK) != 0;
-    if (flags & RTX_FLAG_EXACT_DIVIDE) {
-        launch_traverse(sc->d, rays, pp->hits, pool, tmin, tmax, pp->ctl.p, count_work, true, s);
-    } else if ((flags & RTX_FLAG_F64_FILTER) || !sc->f32_ok) {
-        launch_traverse(sc->d, rays, pp->hits, pool, tmin, tmax, pp->ctl.p, count_work, false, s);
-    } else {
-        const uint32_t mode = lds_mode_for(sc, flags);
-        launch_traverse_f32(sc->d, rays, pp->hits, pool, tmin, tmax, pp->ctl.p, count_work, mode, s);
-    }
-}
-
 static int read_counters(PathPool* pp, hipStream_t s, rtx_stats* stats) {
     DRenderCtl h;
     HIP_TRY(hipMemcpyAsync(&h, pp->ctl.p, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -430,7 +378,7 @@ int rtx_trace_closest(rtx_scene* sc, const double* org, const double* dir, uint6
     // the batch as it lies in the state buffer, cut into one piece per wave
     const DPool pool{nullptr, n_sub, (uint32_t)sub_capacity, (uint32_t)n};
     HIP_TRY(hipEventRecord(sc->ev0, s));
-    run_traverse(sc, pp, pp->state[0], pool, tmin, tmax, flags, s);
+    run_traverse(sc, pp->state[0], pp->hits, pool, tmin, tmax, flags, pp->ctl.p, s);
     HIP_TRY(hipEventRecord(sc->ev1, s));
     launch_user_ids(sc->d.rec_user_id, sc->d.n_spheres, pp->hits.prim, n, s);
     HIP_TRY(hipGetLastError());
@@ -505,6 +453,7 @@ struct LaneRun {
     size_t n_evs = 0;       // kernel timing events used
     uint32_t polls = 0;     // polls enqueued
     bool done = false;
+    DRenderCtl h_ctl{};     // source of the lane's asynchronous control-block upload: lives until the lane has drained
 };
 
 }  // namespace
@@ -634,10 +583,9 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         L.pool = DPool{L.live, L.n_sub, L.sub_capacity, 0u};
         hipStream_t ls = L.pp->stream;
         HIP_TRY(hipStreamWaitEvent(ls, sc->ev0, 0));   // after whatever the caller queued on `stream`
-        DRenderCtl h{};
-        h.next_path[0] = first;
-        h.total_paths = last;
-        HIP_TRY(hipMemcpyAsync(L.pp->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, ls));
+        L.h_ctl.next_path[0] = first;
+        L.h_ctl.total_paths = last;
+        HIP_TRY(hipMemcpyAsync(L.pp->ctl.p, &L.h_ctl, sizeof(L.h_ctl), hipMemcpyHostToDevice, ls));
         HIP_TRY(hipMemsetAsync(L.pp->ctl.p + 1, 0, 3 * sizeof(DRenderCtl), ls));
         HIP_TRY(hipMemsetAsync(L.pp->counters.p, 0, 3 * (size_t)L.n_sub * sizeof(uint32_t), ls));
         L.pp->h_poll[0] = L.pp->h_poll[1] = 1u;
@@ -668,7 +616,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
             }
             launch_generate(dcam, pp->state[cur], ctl, L.surv[cur], L.live, L.n_sub, L.sub_capacity, cur, seed, spp_begin, ls);
             if (time_kernels) (void)hipEventRecord(e1, ls);
-            run_traverse(sc, pp, pp->state[cur], L.pool, 0.001, INFINITY, flags, ls);   // Interval(0.001, inf), camera.rs:194
+            run_traverse(sc, pp->state[cur], pp->hits, L.pool, 0.001, INFINITY, flags, pp->ctl.p, ls);   // Interval(0.001, inf), camera.rs:194
             if (time_kernels) (void)hipEventRecord(e2, ls);
             launch_shade(sc->d, dcam, pp->state[cur], pp->hits, L.pool, pp->state[nxt], L.surv[nxt], seed, d_accum, ls);
             if (time_kernels) (void)hipEventRecord(e3, ls);
@@ -680,7 +628,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
                 hipEvent_t a, b, c;
                 (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventCreate(&c);
                 (void)hipEventRecord(a, ls);
-                for (uint32_t q = 0; q < reps; ++q) run_traverse(sc, pp, pp->state[cur], L.pool, 0.001, INFINITY, flags, ls);
+                for (uint32_t q = 0; q < reps; ++q) run_traverse(sc, pp->state[cur], pp->hits, L.pool, 0.001, INFINITY, flags, pp->ctl.p, ls);
                 (void)hipEventRecord(b, ls);
                 for (uint32_t q = 0; q < reps; ++q)
                     launch_shade(sc->d, dcam, pp->state[cur], pp->hits, L.pool, pp->state[nxt], L.surv[nxt], seed, d_accum, ls);
