@@ -13,6 +13,8 @@ pub const RTX_ERR_NO_DEVICE: c_int = -2;
 pub const RTX_ERR_HIP: c_int = -3;
 pub const RTX_ERR_OOM: c_int = -4;
 pub const RTX_ERR_BUILD: c_int = -5;
+pub const RTX_ERR_RCCL: c_int = -6;
+pub const RTX_MULTI_MAX_GPUS: usize = 16;
 
 // enum rtx_geom_kind (enum Geometry, src/geometry.rs:25-47)
 pub const RTX_SPHERE: u32 = 0;
@@ -112,7 +114,27 @@ pub struct rtx_build_stats {
 }
 
 #[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct rtx_multi_stats {
+    pub rays: u64,
+    pub paths: u64,
+    pub n_gpus: u32,
+    pub collective_ranks: u32,
+    pub ms_frame: f64,
+    pub ms_reduce: f64,
+    pub spp_begin: [u32; RTX_MULTI_MAX_GPUS],
+    pub spp_count: [u32; RTX_MULTI_MAX_GPUS],
+    pub ms_render: [f64; RTX_MULTI_MAX_GPUS],
+    pub ms_device: [f64; RTX_MULTI_MAX_GPUS],
+}
+
+#[repr(C)]
 pub struct rtx_scene {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct rtx_multi {
     _private: [u8; 0],
 }
 
@@ -188,6 +210,26 @@ extern "C" {
         out_len: *mut u64,
         stats: *mut rtx_stats,
     ) -> c_int;
+    pub fn rtx_multi_create(desc: *const rtx_scene_desc, n_gpus: c_int, out: *mut *mut rtx_multi) -> c_int;
+    pub fn rtx_multi_destroy(multi: *mut rtx_multi);
+    pub fn rtx_multi_render(
+        multi: *mut rtx_multi,
+        cam: *const rtx_camera,
+        seed: u64,
+        flags: u32,
+        out_rgb: *mut f64,
+        stats: *mut rtx_multi_stats,
+    ) -> c_int;
+    pub fn rtx_multi_image(multi: *const rtx_multi) -> *const f64;
+    pub fn rtx_render_multi(
+        desc: *const rtx_scene_desc,
+        cam: *const rtx_camera,
+        seed: u64,
+        n_gpus: c_int,
+        flags: u32,
+        out_rgb: *mut f64,
+        stats: *mut rtx_multi_stats,
+    ) -> c_int;
     pub fn rtx_selftest_math(op: c_int, a: *const f64, b: *const f64, n: u64, out: *mut f64) -> c_int;
     pub fn rtx_selftest_rng(seed: u64, pixel: u32, sample: u32, n: u32, out: *mut f64) -> c_int;
 }
@@ -203,5 +245,6 @@ mod layout {
         assert_eq!(size_of::<rtx_camera>(), 16 + 8 + 24 + 8 + 6 * 24);
         assert_eq!(size_of::<rtx_stats>(), 7 * 8 + 4 * 8);
         assert_eq!(size_of::<rtx_build_stats>(), 8 + 8 + 8 + 8);
+        assert_eq!(size_of::<rtx_multi_stats>(), 16 + 8 + 16 + RTX_MULTI_MAX_GPUS * 24);
     }
 }

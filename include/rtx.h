@@ -31,7 +31,8 @@ enum rtx_status {
     RTX_ERR_NO_DEVICE = -2,
     RTX_ERR_HIP = -3,
     RTX_ERR_OOM = -4,
-    RTX_ERR_BUILD = -5
+    RTX_ERR_BUILD = -5,
+    RTX_ERR_RCCL = -6
 };
 
 /* enum Geometry, src/geometry.rs:25-47 */
@@ -141,6 +142,10 @@ int rtx_device_count(void);
  * holding `world: BVH` across the render (src/runner.rs:27-31).  The caller
  * keeps ownership of every array in `desc`; they are not referenced after
  * the call returns. */
+/* A scene handle is used by ONE host thread at a time: all calls on it share
+ * its path pool, control block and timing events (the reference calls
+ * render once, from the main thread, src/runner.rs:31).  Different handles
+ * may be used from different threads concurrently. */
 int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out);
 void rtx_scene_destroy(rtx_scene* scene);
 
@@ -215,6 +220,52 @@ int rtx_render(rtx_scene* scene, const rtx_camera* cam, uint64_t seed, uint32_t 
  * (host, [H][W][3]) or out_text (host, `capacity` bytes) may be NULL. */
 int rtx_render_ppm(rtx_scene* scene, const rtx_camera* cam, uint64_t seed, uint32_t flags, double* out_rgb,
                    char* out_text, uint64_t capacity, uint64_t* out_len, rtx_stats* stats);
+
+/* ---- one frame on several GPUs of a node, from one process ----
+ * Replaces `camera.initialize().render(&world)` of RenderRunner::run
+ * (src/runner.rs:23-41) when the caller has more than one GPU: the sample loop
+ * (src/camera.rs:133-151) is split by sample index, device g of n renders
+ * samples [begin_g, begin_g + count_g) of every pixel (500 over 8 devices ->
+ * 63,63,63,63,62,62,62,62) with the scene replicated in its HBM, and the f64
+ * accumulation buffers are summed onto device 0 with one RCCL reduce over xGMI
+ * (the reference's per-pixel `.reduce(|| ZERO, |a, b| a + b)`,
+ * src/camera.rs:147-148), then multiplied by 1/spp there.  Sample s of pixel p
+ * uses RNG stream (seed, p, s) whatever n is, so the image does not depend on
+ * n up to the order of the f64 additions.  librccl is loaded on first use;
+ * RTX_ERR_RCCL reports its absence or its errors. */
+#define RTX_MULTI_MAX_GPUS 16
+typedef struct rtx_multi rtx_multi;
+typedef struct rtx_multi_stats {
+    uint64_t rays;                             /* over all devices */
+    uint64_t paths;
+    uint32_t n_gpus;
+    uint32_t collective_ranks;                 /* ranks of the communicator the reduce ran on (ncclCommCount) */
+    double   ms_frame;                         /* host wall clock: first device call of the frame -> scaled image resident on device 0 */
+    double   ms_reduce;                        /* host wall clock: last render finished -> reduce and 1/spp scaling complete */
+    uint32_t spp_begin[RTX_MULTI_MAX_GPUS];    /* sample range of each device */
+    uint32_t spp_count[RTX_MULTI_MAX_GPUS];
+    double   ms_render[RTX_MULTI_MAX_GPUS];    /* host wall clock of each device's render call */
+    double   ms_device[RTX_MULTI_MAX_GPUS];    /* device time of it (rtx_stats.ms_total) */
+} rtx_multi_stats;
+
+/* Set-up, outside any timed region: the scene uploaded to devices 0..n_gpus-1,
+ * one stream per device, and the RCCL communicator clique (ncclCommInitAll,
+ * hundreds of milliseconds).  1 <= n_gpus <= rtx_device_count() and
+ * <= RTX_MULTI_MAX_GPUS.  The arrays of `desc` are not referenced after the call. */
+int rtx_multi_create(const rtx_scene_desc* desc, int n_gpus, rtx_multi** out);
+void rtx_multi_destroy(rtx_multi* multi);
+/* One frame: one host thread per device runs rtx_render_accumulate on its
+ * sample range; when all have finished, the calling thread issues the reduce
+ * (one ncclGroupStart/End over the devices' ranks) and the 1/spp scaling.  out_rgb: host, [H][W][3] f64
+ * linear RGB already multiplied by 1/spp, or NULL to leave the image on
+ * device 0 (rtx_multi_image).  stats may be NULL.  One caller at a time per handle. */
+int rtx_multi_render(rtx_multi* multi, const rtx_camera* cam, uint64_t seed, uint32_t flags,
+                     double* out_rgb, rtx_multi_stats* stats);
+/* Device-0 address of the last frame's image ([H][W][3] f64), valid until the next call on the handle. */
+const double* rtx_multi_image(const rtx_multi* multi);
+/* rtx_multi_create + rtx_multi_render + rtx_multi_destroy in one call (pays the set-up every time). */
+int rtx_render_multi(const rtx_scene_desc* desc, const rtx_camera* cam, uint64_t seed, int n_gpus,
+                     uint32_t flags, double* out_rgb, rtx_multi_stats* stats);
 
 /* Device arithmetic self-test hooks used by the parity tests:
  * op 0: out[i] = a[i] / b[i]; op 1: out[i] = sqrt(a[i]);

@@ -92,6 +92,18 @@ class Stats(C.Structure):  # rtx_stats
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+MULTI_MAX_GPUS = 16
+
+
+class MultiStats(C.Structure):  # rtx_multi_stats
+    _fields_ = [
+        ("rays", C.c_uint64), ("paths", C.c_uint64), ("n_gpus", C.c_uint32), ("collective_ranks", C.c_uint32),
+        ("ms_frame", C.c_double), ("ms_reduce", C.c_double),
+        ("spp_begin", C.c_uint32 * MULTI_MAX_GPUS), ("spp_count", C.c_uint32 * MULTI_MAX_GPUS),
+        ("ms_render", C.c_double * MULTI_MAX_GPUS), ("ms_device", C.c_double * MULTI_MAX_GPUS),
+    ]
+
+
 class BuildStats(C.Structure):  # rtx_build_stats
     _fields_ = [
         ("levels", C.c_uint32), ("n_nodes", C.c_uint32), ("ms_sort", C.c_double), ("ms_levels", C.c_double),
@@ -106,7 +118,7 @@ class BuildStats(C.Structure):  # rtx_build_stats
 ABI_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_trace_closest",
     "rtx_primary_rays", "rtx_render_accumulate", "rtx_scale", "rtx_quantize", "rtx_render", "rtx_selftest_math",
-    "rtx_selftest_rng", "rtx_bvh_build", "rtx_ppm_text_bound", "rtx_ppm_text", "rtx_render_ppm",
+    "rtx_selftest_rng", "rtx_bvh_build", "rtx_multi_create", "rtx_multi_destroy", "rtx_multi_render", "rtx_multi_image", "rtx_render_multi", "rtx_ppm_text_bound", "rtx_ppm_text", "rtx_render_ppm",
     "rth_last_error", "rth_bvh_build", "rth_bvh_build_device", "rth_run_device_build", "rth_example", "rth_bvh_desc", "rth_bvh_destroy", "rth_camera_initialize", "rth_run",
 ]
 
@@ -122,6 +134,13 @@ _lib.rtx_render_accumulate.argtypes = [C.c_void_p, _p(Camera), C.c_uint64, C.c_u
 _lib.rtx_scale.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p]
 _lib.rtx_quantize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
 _lib.rtx_render.argtypes = [C.c_void_p, _p(Camera), C.c_uint64, C.c_uint32, _dp, _p(Stats)]
+_lib.rtx_multi_create.argtypes = [_p(SceneDesc), C.c_int, _p(C.c_void_p)]
+_lib.rtx_multi_destroy.argtypes = [C.c_void_p]
+_lib.rtx_multi_destroy.restype = None
+_lib.rtx_multi_render.argtypes = [C.c_void_p, _p(Camera), C.c_uint64, C.c_uint32, _dp, _p(MultiStats)]
+_lib.rtx_multi_image.argtypes = [C.c_void_p]
+_lib.rtx_multi_image.restype = C.c_void_p
+_lib.rtx_render_multi.argtypes = [_p(SceneDesc), _p(Camera), C.c_uint64, C.c_int, C.c_uint32, _dp, _p(MultiStats)]
 _lib.rtx_selftest_math.argtypes = [C.c_int, _dp, _dp, C.c_uint64, _dp]
 _lib.rtx_selftest_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _dp]
 _lib.rth_bvh_build.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, _p(C.c_void_p)]
@@ -304,6 +323,37 @@ class Scene:
     def close(self):
         if self._h:
             _lib.rtx_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiScene:
+    """``rtx_multi_*``: the scene replicated on the first `n_gpus` devices of this process and their RCCL communicator."""
+
+    def __init__(self, bvh, n_gpus):
+        desc = bvh.desc if isinstance(bvh, HostBVH) else bvh
+        self._keep = bvh
+        self._h = C.c_void_p()
+        _check(_lib.rtx_multi_create(C.byref(desc), n_gpus, C.byref(self._h)))
+
+    def render(self, cam, seed=0, flags=0, to_host=True):
+        """One frame; returns (image[H,W,3] already x 1/spp or None, MultiStats)."""
+        img = np.empty((cam.image_height, cam.image_width, 3), np.float64) if to_host else None
+        st = MultiStats()
+        _check(_lib.rtx_multi_render(self._h, C.byref(cam), seed, flags, _ptr(img, _dp) if to_host else None, C.byref(st)))
+        return img, st
+
+    def image_ptr(self):
+        return _lib.rtx_multi_image(self._h)
+
+    def close(self):
+        if self._h:
+            _lib.rtx_multi_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

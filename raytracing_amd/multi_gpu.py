@@ -43,6 +43,18 @@ def reduce_accum(accum, world, dst=0):
     return accum
 
 
+def collective_ranks(device=None):
+    """How many ranks the frame's collective reaches: every rank contributes 1.0 to a one-element buffer that goes
+    through the same sum-reduce as the accumulation buffers; the root's result is returned on every rank (broadcast).
+    1 without a process group.  Also brings the communicator up before anything is timed."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    reduce_accum(one, dist.get_world_size())
+    dist.broadcast(one, src=0)
+    return int(round(float(one.item())))
+
+
 def render_frame(render_accumulate, accum, rank, world, spp, scale=None):
     """One frame on `world` ranks.
 

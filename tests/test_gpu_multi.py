@@ -1,0 +1,48 @@
+"""rtx_multi_*: the N-GPU frame from one process (one host thread per device, ncclCommInitAll, one ncclReduce),
+through the C ABI.  A one-GPU box can only run the world of one; that still goes through the communicator set-up,
+the reduce and the scaling, and must give the single-GPU image."""
+import numpy as np
+import pytest
+
+from raytracing_amd import scenes as S
+
+pytestmark = pytest.mark.gpu
+
+
+def test_multi_render_on_the_visible_devices_equals_single_device_render(rt):
+    surfaces, cam = S.cover_spheres()
+    cam = dict(cam, image_width=256, samples_per_pixel=9)
+    bvh = rt.HostBVH(surfaces)
+    icam = rt.camera_initialize(cam)
+    want, st = rt.Scene(bvh).render(icam, 17)
+    for n in sorted({1, min(rt.device_count(), 2), rt.device_count()}):
+        multi = rt.MultiScene(bvh, n)
+        for _ in range(2):   # the handle is reusable; the second frame starts from cleared buffers
+            img, ms = multi.render(icam, 17)
+            assert (ms.n_gpus, ms.collective_ranks) == (n, n)
+            assert (ms.rays, ms.paths) == (st.rays, st.paths)
+            assert list(ms.spp_count[:n]) == [9 // n + (1 if g < 9 % n else 0) for g in range(n)]
+            assert sum(ms.spp_count[:n]) == 9 and ms.spp_begin[0] == 0
+            np.testing.assert_allclose(img, want, rtol=1e-13, atol=0)   # same radiance values, summed in another order
+            assert ms.ms_frame > 0 and ms.ms_frame >= max(ms.ms_device[:n])
+        assert multi.image_ptr()
+        multi.close()
+
+
+def test_one_shot_render_multi_and_errors(rt):
+    import ctypes as C
+
+    surfaces, cam = S.simple_scene()
+    bvh = rt.HostBVH(surfaces)
+    icam = rt.camera_initialize(dict(cam, image_width=64, samples_per_pixel=3))
+    want, _ = rt.Scene(bvh).render(icam, 2)
+    img = np.empty_like(want)
+    ms = rt.MultiStats()
+    rc = rt._lib.rtx_render_multi(C.byref(bvh.desc), C.byref(icam), 2, 1, 0, img.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ms))
+    assert rc == 0, rt._lib.rtx_last_error()
+    np.testing.assert_allclose(img, want, rtol=1e-13, atol=0)
+    assert ms.collective_ranks == 1
+    for bad in (0, -1, rt.device_count() + 1, 1000):
+        with pytest.raises(rt.RtxError) as e:
+            rt.MultiScene(bvh, bad)
+        assert e.value.code == -1

@@ -34,6 +34,7 @@ def test_struct_layouts_match_headers(rt, oracle):
     assert ctypes.sizeof(rt.CameraConfig) == ctypes.sizeof(oracle.CameraConfig) == 8 + 16 + 8 + 72 + 16 + 24
     assert ctypes.sizeof(rt.Stats) == 7 * 8 + 4 * 8
     assert ctypes.sizeof(rt.SceneDesc) == 16 + 17 * 8
+    assert ctypes.sizeof(rt.MultiStats) == 16 + 8 + 16 + rt.MULTI_MAX_GPUS * (4 + 4 + 8 + 8)
     assert rt.SURFACE_DTYPE.itemsize == 120
 
 
@@ -168,10 +169,10 @@ def test_rust_bindings_declare_the_whole_abi():
     rust = open(os.path.join(ROOT, "bindings", "rust", "rtx-sys", "src", "lib.rs")).read()
     for name in declared_functions("rtx.h"):
         assert re.search(r"pub fn %s\s*\(" % name, rust), f"{name} missing from rtx-sys"
-    for struct in ("rtx_scene_desc", "rtx_camera", "rtx_stats", "rtx_build_stats"):
+    for struct in ("rtx_scene_desc", "rtx_camera", "rtx_stats", "rtx_build_stats", "rtx_multi_stats"):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-        c_fields = re.findall(r"(\w+)(?:\[\d+\])?\s*;", body)
+        c_fields = re.findall(r"(\w+)(?:\[\w+\])?\s*;", body)
         r_body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, rust, re.S).group(1)
         r_fields = re.findall(r"pub (\w+)\s*:", r_body)
         assert c_fields == r_fields, (struct, c_fields, r_fields)

@@ -49,12 +49,13 @@ def _worker(rank, world, port, out_path):
             accum.add_(torch.from_numpy(part))
             return ctr
 
+        seen = mg.collective_ranks()   # ranks that take part in the frame's reduce
         scale = icam.pixel_samples_scale
         stats, (begin, count) = mg.render_frame(render_accumulate, accum, rank, world, SPP, scale=lambda a: a.mul_(scale))
         rays = torch.tensor([float(stats.rays if stats is not None else 0), float(count)], dtype=torch.float64)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         if rank == 0:
-            np.savez(out_path, image=accum.numpy(), rays=rays.numpy())
+            np.savez(out_path, image=accum.numpy(), rays=rays.numpy(), ranks_in_collective=seen)
     finally:
         dist.destroy_process_group()
 
@@ -78,6 +79,7 @@ def test_spp_split_and_reduce_matches_single_rank(tmp_path, world):
     # every sample index was rendered exactly once, and the ray count is additive
     assert int(got["rays"][1]) == SPP
     assert int(got["rays"][0]) == ctr.rays
+    assert int(got["ranks_in_collective"]) == world
 
 
 def test_spp_range_partitions():
