@@ -7,7 +7,7 @@ EXTRA    ?=
 HIPFLAGS ?= $(EXTRA) -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -munsafe-fp-atomics -Wall -Wno-unused-result
 
 LIB  := raytracing_amd/librtx.so
-SRCS := raytracing_amd/csrc/rtx_kernels.hip raytracing_amd/csrc/rtx_build.hip raytracing_amd/csrc/rtx_output.hip raytracing_amd/csrc/rtx_api.cpp raytracing_amd/csrc/rtx_multi.cpp raytracing_amd/host/rtx_host.cpp
+SRCS := raytracing_amd/csrc/rtx_kernels.hip raytracing_amd/csrc/rtx_build.hip raytracing_amd/csrc/rtx_output.hip raytracing_amd/csrc/rtx_noalloc.hip raytracing_amd/csrc/rtx_api.cpp raytracing_amd/csrc/rtx_multi.cpp raytracing_amd/host/rtx_host.cpp
 OBJS := $(patsubst %,build/%.o,$(notdir $(SRCS)))
 HDRS := raytracing_amd/csrc/rtx_internal.h include/rtx.h include/rtx_host.h raytracing_amd/csrc/rtx_device.h raytracing_amd/csrc/rtx_kernels.h raytracing_amd/csrc/rtx_scan.h raytracing_amd/host/raytracing.hpp raytracing_amd/host/examples.hpp
 vpath %.hip raytracing_amd/csrc

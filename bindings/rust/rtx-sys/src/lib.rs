@@ -5,6 +5,7 @@
 use std::os::raw::{c_char, c_int, c_void};
 
 pub const RTX_NONE: u32 = 0xFFFF_FFFF;
+pub const RTX_TRACE_DEVICE_MAX_RAYS: u64 = 1 << 20;
 
 // enum rtx_status
 pub const RTX_OK: c_int = 0;
@@ -166,6 +167,18 @@ extern "C" {
         out_id: *mut u32,
         out_t: *mut f64,
         stats: *mut rtx_stats,
+    ) -> c_int;
+    pub fn rtx_trace_closest_device(
+        scene: *mut rtx_scene,
+        d_org: *const f64,
+        d_dir: *const f64,
+        n: u64,
+        tmin: f64,
+        tmax: f64,
+        flags: u32,
+        d_out_id: *mut u32,
+        d_out_t: *mut f64,
+        stream: *mut c_void,
     ) -> c_int;
     pub fn rtx_primary_rays(cam: *const rtx_camera, seed: u64, sample: u32, org: *mut f64, dir: *mut f64) -> c_int;
     pub fn rtx_render_accumulate(

@@ -174,6 +174,29 @@ int rtx_trace_closest(rtx_scene* scene, const double* org, const double* dir, ui
                       double tmin, double tmax, uint32_t flags,
                       uint32_t* out_id, double* out_t, rtx_stats* stats);
 
+/* No counterpart in the reference.  rtx_trace_closest for callers that cannot
+ * allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  Same kernels, same results, but
+ *   - org/dir/out_id/out_t are DEVICE memory of the scene's device ([n][3],
+ *     [n][3], [n], [n]);
+ *   - the per-component ray arrays, hit records and control block the kernels
+ *     work on live in a fixed scratch array inside the library's code object
+ *     (about 60 MiB per GPU, held until the process ends) instead of buffers
+ *     allocated on demand, so n is limited to RTX_TRACE_DEVICE_MAX_RAYS (larger
+ *     batches are rejected with RTX_ERR_BAD_ARG: split them);
+ *   - the work is enqueued on `stream` (a hipStream_t, NULL = default stream)
+ *     and the call returns without waiting; outputs are complete when the
+ *     stream has reached that point;
+ *   - flags select the tier of the box test only (RTX_FLAG_EXACT_DIVIDE,
+ *     RTX_FLAG_F64_FILTER, RTX_FLAG_NO_LDS); there is no stats output.
+ * The call makes no hipMalloc/hipFree.  Every call on a GPU uses that GPU's one
+ * scratch array: calls that overlap on one GPU (two streams, two threads, two
+ * scenes) race; order them. */
+#define RTX_TRACE_DEVICE_MAX_RAYS (1u << 20)
+int rtx_trace_closest_device(rtx_scene* scene, const double* d_org, const double* d_dir, uint64_t n,
+                             double tmin, double tmax, uint32_t flags,
+                             uint32_t* d_out_id, double* d_out_t, void* stream);
+
 /* Primary rays of sample index `sample` for every pixel, as the render
  * kernels generate them (sample_square + get_ray, src/camera.rs:164-182).
  * org/dir: host, [W*H][3]. */

@@ -32,6 +32,7 @@ FLAG_TIME_KERNELS = 2
 FLAG_EXACT_DIVIDE = 4
 FLAG_F64_FILTER = 8
 FLAG_NO_LDS = 16
+TRACE_DEVICE_MAX_RAYS = 1 << 20
 
 BISECT, MIDPOINT, SAH_EQUAL_SIZE, SAH_PER_SURFACE = 0, 1, 2, 3
 
@@ -116,7 +117,7 @@ class BuildStats(C.Structure):  # rtx_build_stats
 
 # every symbol include/rtx.h and include/rtx_host.h declare
 ABI_SYMBOLS = [
-    "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_trace_closest",
+    "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_trace_closest", "rtx_trace_closest_device",
     "rtx_primary_rays", "rtx_render_accumulate", "rtx_scale", "rtx_quantize", "rtx_render", "rtx_selftest_math",
     "rtx_selftest_rng", "rtx_bvh_build", "rtx_multi_create", "rtx_multi_destroy", "rtx_multi_render", "rtx_multi_image", "rtx_render_multi", "rtx_ppm_text_bound", "rtx_ppm_text", "rtx_render_ppm",
     "rth_last_error", "rth_bvh_build", "rth_bvh_build_device", "rth_run_device_build", "rth_example", "rth_bvh_desc", "rth_bvh_destroy", "rth_camera_initialize", "rth_run",
@@ -129,6 +130,7 @@ _lib.rtx_scene_create.argtypes = [_p(SceneDesc), _p(C.c_void_p)]
 _lib.rtx_scene_destroy.argtypes = [C.c_void_p]
 _lib.rtx_scene_destroy.restype = None
 _lib.rtx_trace_closest.argtypes = [C.c_void_p, _dp, _dp, C.c_uint64, C.c_double, C.c_double, C.c_uint32, _u32p, _dp, _p(Stats)]
+_lib.rtx_trace_closest_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.rtx_primary_rays.argtypes = [_p(Camera), C.c_uint64, C.c_uint32, _dp, _dp]
 _lib.rtx_render_accumulate.argtypes = [C.c_void_p, _p(Camera), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, _p(Stats)]
 _lib.rtx_scale.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p]
@@ -306,6 +308,11 @@ class Scene:
         st = Stats()
         _check(_lib.rtx_trace_closest(self._h, _ptr(org, _dp), _ptr(direction, _dp), n, tmin, tmax, flags, _ptr(ids, _u32p), _ptr(t, _dp), C.byref(st)))
         return ids, t, st
+
+    def trace_closest_device(self, d_org_ptr, d_dir_ptr, n, d_out_id_ptr, d_out_t_ptr, tmin=0.001, tmax=float("inf"), flags=0, stream=None):
+        """``rtx_trace_closest_device``: the same batch on device buffers, enqueued on `stream`, without any allocation."""
+        _check(_lib.rtx_trace_closest_device(self._h, C.c_void_p(d_org_ptr), C.c_void_p(d_dir_ptr), n, tmin, tmax, flags,
+                                             C.c_void_p(d_out_id_ptr), C.c_void_p(d_out_t_ptr), C.c_void_p(stream or 0)))
 
     def render(self, cam, seed=0, flags=0):
         """Full render; returns (image[H,W,3] f64 linear, already x 1/spp, stats)."""

@@ -327,6 +327,9 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     sc->f32_ok = f32_ok && filter_ok;
     if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
         return bail(fail(RTX_ERR_HIP, "hipEventCreate failed"));
+    // Set-up of the allocation-free closest-hit entry: where this device keeps its copy of the scratch array.
+    // (A failure here is not the scene's: rtx_trace_closest_device looks again and reports it.)
+    (void)noalloc_setup_current_device();
     *out = sc;
     return RTX_OK;
 }

@@ -118,4 +118,7 @@ namespace rtx {
 void run_traverse(const rtx_scene* sc, const DState& rays, const DHits& hits, const DPool& pool, double tmin, double tmax,
                   uint32_t flags, DRenderCtl* ctl, hipStream_t s);
 
+// The device's copy of the scratch array of rtx_trace_closest_device; looked up once per device.
+int noalloc_setup_current_device();
+
 }  // namespace rtx
