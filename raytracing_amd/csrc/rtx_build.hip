@@ -195,7 +195,12 @@ __device__ __forceinline__ double split_cost(const double* left, uint32_t n_left
     const double parent = area_factor(bb);
     const double p_left = area_factor(left) / parent;
     const double p_right = area_factor(right) / parent;
-    return 1.0 + p_left * (double)n_left + p_right * (double)n_right;
+    const double cost = 1.0 + p_left * (double)n_left + p_right * (double)n_right;
+    // A parent box without area (zero-radius spheres on a line) makes the cost 0/0.  total_cmp orders NaNs by their sign,
+    // and the default NaN of the hosts the reference and the host builder run on (x86-64) is the negative one, which
+    // min_by ranks lowest; this device's default NaN is the positive one.  Every NaN cost takes the host's form, so
+    // that both builders pick the same plane for such a segment.
+    return cost != cost ? __longlong_as_double((long long)0xFFF8000000000000ull) : cost;
 }
 
 __device__ __forceinline__ double cost_of_split(const DBuild& B, uint32_t axis, uint32_t a, uint32_t b, uint32_t k) {

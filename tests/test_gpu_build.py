@@ -156,6 +156,17 @@ def test_failures_match_the_host_builder(rt):
         rt.HostBVH(lattice(2, 2, 2), 2, 1, device=True)   # one bucket: no candidate plane
 
 
+@pytest.mark.parametrize("strategy,buckets", STRATEGIES, ids=STRATEGY_IDS)
+def test_parent_box_without_area(rt, strategy, buckets):
+    """Zero-radius spheres on a line: the parent's area factor is 0, every SAH cost is 0/0.  f64::total_cmp orders NaNs
+    by sign; the host builder (like the reference on x86-64) gets the negative default NaN, the device the positive one
+    unless it takes the host's form: both builders must still pick the same planes (or fail alike)."""
+    line = S.pack([sph(float(i), 0.0, 0.0, 0.0) for i in (3, 0, 5, 1, 4, 2, 7, 6)])
+    compare(rt, line, strategy, buckets)
+    diag = S.pack([sph(0.5 * i, 0.0, 2.0, 0.0) for i in range(33)] + [sph(40.0, 0.0, 2.0, 0.25)])   # area appears only near the root
+    compare(rt, diag, strategy, buckets)
+
+
 def test_single_and_empty(rt):
     one = S.pack([sph(0, 0, 0, 1)])
     compare(rt, one, 3)
