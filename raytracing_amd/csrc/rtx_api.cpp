@@ -275,6 +275,40 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
         nodes32[i].miss = nd.miss * 32u;
     }
 
+    // Quantised half-size records for trees that are walked from global memory: a grid of 2^16 steps over the extent of
+    // all boxes per axis, every plane rounded to the nearest step.  The walk's error bound rests on
+    // |q_org + q * delta - plane| <= delta / 2 (1 + 1e-4): checked here plane by plane, and a scene that fails it
+    // (extents too small against their offset for f64 to resolve the steps) keeps the f32 records.
+    std::vector<DNode16> nodes16;
+    double q_org[3] = {0, 0, 0};
+    float q_delta[3] = {0, 0, 0};
+    bool q16_ok = f32_ok && filter_ok && n > 0;
+    if (q16_ok) {
+        nodes16.resize(n);
+        for (int a = 0; a < 3 && q16_ok; ++a) {
+            double lo = nodes[0].bmin[a], hi = nodes[0].bmax[a];
+            for (uint32_t i = 1; i < n; ++i) {
+                lo = std::fmin(lo, nodes[i].bmin[a]);
+                hi = std::fmax(hi, nodes[i].bmax[a]);
+            }
+            q_org[a] = lo;
+            q_delta[a] = (float)((hi - lo) / 65534.0);   // one step of slack for the rounding of delta to f32
+            if (!(hi >= lo) || !std::isfinite(q_delta[a]) || (hi > lo && !(q_delta[a] >= 1e-30f))) q16_ok = false;
+            const double dl = (double)q_delta[a];
+            for (uint32_t i = 0; i < n && q16_ok; ++i) {
+                const double planes[2] = {nodes[i].bmin[a], nodes[i].bmax[a]};
+                for (int k = 0; k < 2; ++k) {
+                    const double q = dl > 0.0 ? std::nearbyint((planes[k] - lo) / dl) : 0.0;
+                    if (!(q >= 0.0 && q <= 65535.0) || !(std::fabs(lo + q * dl - planes[k]) <= 0.50005 * dl)) q16_ok = false;
+                    else nodes16[i].q[2 * a + k] = (uint16_t)q;
+                }
+            }
+        }
+        for (uint32_t i = 0; i < n && q16_ok; ++i)
+            nodes16[i].link = nodes[i].prim != NONE ? nodes[i].prim : (NODE16_INTERNAL | nodes[i].miss);
+        if (!q16_ok) nodes16.clear();
+    }
+
     rtx_scene* sc = new rtx_scene();
     auto bail = [&](int code) {
         delete sc;
@@ -295,6 +329,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     UP(spheres, spheres);
     UP(planars, planars);
     UP(nodes32, nodes32);
+    UP(nodes16, nodes16);
     UP(boxes64, boxes64);
     UP(rec_user_id, rec_user_id);
     UP(shade_recs, shade_recs);
@@ -319,6 +354,15 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     sc->d.refill_at = env_u32("RTX_REFILL_AT", planar_scene && small_scene ? 16u : 32u);
     if (sc->d.refill_at > 64u) sc->d.refill_at = 64u;
     sc->d.nodes32 = sc->nodes32.p;
+    sc->d.nodes16 = q16_ok ? sc->nodes16.p : nullptr;
+    for (int a = 0; a < 3; ++a) {
+        sc->d.q_org[a] = q_org[a];
+        sc->d.q_delta[a] = q_delta[a];
+    }
+    // Where the walk is bound by the number of lines fetched (trees well beyond one L2, 4 MiB per XCD), eight records per line beat
+    // four; smaller trees keep the f32 records, whose test is decided more often.  RTX_NODE16 = 0 / 1 overrides.
+    const size_t node16_min = env_u32("RTX_NODE16_MIN_BYTES", 4u << 20);
+    sc->d.use16 = q16_ok ? env_u32("RTX_NODE16", (size_t)n * sizeof(DNode32) > node16_min ? 1u : 0u, true) : 0u;
     sc->d.boxes64 = sc->boxes64.p;
     sc->d.n_spheres = n_spheres;
     sc->d.n_planars = (uint32_t)planars.size();

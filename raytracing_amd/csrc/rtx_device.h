@@ -40,6 +40,18 @@ struct __attribute__((aligned(32))) DNode32 {
     uint32_t leaf;    // NONE for an internal node, else the surface code (make_code)
 };
 static_assert(sizeof(DNode32) == 32, "f32 node record must be 32 bytes");
+// Half-size copy of a node for trees that are walked from global memory (far larger than LDS and L2).  There the
+// walk is bound by how many lines the memory system can deliver per second (one request per visit that misses L2,
+// whatever its size), so the records are made small enough for eight of them to share a 128-byte line: the box planes
+// as 16-bit steps of a per-scene grid (plane = q_org + q * q_delta per axis, rounded to the nearest step) and ONE link
+// word.  In pre-order a leaf's successor is the next record, so a leaf stores its surface code and an internal node
+// (tag 3 in the two top bits, which no surface code has) the index of its successor.
+struct __attribute__((aligned(16))) DNode16 {
+    uint16_t q[6];    // lo.x, hi.x, lo.y, hi.y, lo.z, hi.z
+    uint32_t link;    // leaf: surface code (make_code); internal: 0xC0000000 | index of the successor record
+};
+static_assert(sizeof(DNode16) == 16, "quantised node record must be 16 bytes");
+constexpr uint32_t NODE16_INTERNAL = 0xC0000000u;
 // The exact box of a node, for the rare visits the f32 tier cannot decide.
 struct __attribute__((aligned(16))) DBox64 {
     double bmin[3];
@@ -103,6 +115,10 @@ struct DScene {
     uint32_t n_spheres, n_planars;
     const DShadeRec* shade_recs;   // spheres by slot, then planars by slot
     const uint32_t* rec_user_id;   // same order: index of the surface in the caller's array
+    const DNode16* nodes16;        // quantised records, or nullptr when the scene has none
+    double q_org[3];               // grid of the quantised planes: plane = q_org + q * q_delta
+    float q_delta[3];
+    uint32_t use16;                // the global-memory walk reads nodes16 instead of nodes32
 };
 
 // State of the paths in flight, struct-of-arrays.  Entry i of every array
@@ -472,8 +488,46 @@ __device__ __forceinline__ void rayf32_init(RayF32& r, V3 o, V3 d, double tmin, 
     r.K = ok ? oi_max * (8.1f * 0x1.0p-24f) + 2e-30f : __builtin_inff();
     rayf32_set_tmax(r, tmax);
 }
-// Returns whether the answer is certain; `hit` is the answer when it is.
-__device__ __forceinline__ bool box_hit_f32(const float p[6], const RayF32& r, bool& hit) {
+// The same tier on the quantised records (DNode16).  The plane of a record is b = q_org + q delta + eps with
+// |eps| <= delta / 2 (1 + 1e-4) (checked plane by plane when the scene is created), so with o' = o - q_org
+//     Q = (b - o) / d = (q delta - o') / d + eps / d.
+// Per ray  s = RN32(RN32(delta) inv32)  and  c = RN32(RN32(o') inv32)  (relative errors at most 4.01u each: see the
+// f32 tier for inv32), and the slab distance is the single fused t~ = RN32(q s - c); q < 2^16 is exact in f32.  Then
+//     |t~ - (q delta - o')/d| <= u |t~| + 4.01u |q delta / d| + 4.01u |o'/d|  <=  5.03u |t~| + 8.04u |c|,
+// using |q delta / d| <= |t~| + |t~ - ..| + |o'/d| and |o'/d| <= |c| (1 + 4.01u), and so with M >= every |t~| of the
+// node, C >= every |c| of the ray and D = max over the axes of RN32(delta) |inv32| (>= 2 |eps / d| / 1.0003):
+//     E = 5.05u M + 8.05u C + 0.5002 D + 1e-30     bounds the error of lo and hi.
+// The rest is the f32 tier's argument with this E: T = 14.2u M' + (16.2u C + 1.001 D + 2e-30) >= 2E + the rounding of
+// tmin, tmax and of the subtractions (4.1u M' as there).  m > T proves the reference's predicate true, m < -T false.
+// The test itself is the f32 tier's (box_hit_tier1) with the steps converted to float as "planes", s as inv, c as oi, and this T.
+constexpr float TIER_F32_COEF = 12.2f * 0x1.0p-24f;
+constexpr float TIER_Q16_COEF = 14.2f * 0x1.0p-24f;
+__device__ __forceinline__ void rayq16_init(RayF32& r, V3 o, V3 d, double tmin, double tmax, const double q_org[3], const float q_delta[3]) {
+    const float dv[3] = {(float)d.x, (float)d.y, (float)d.z};
+    const float ov[3] = {(float)(o.x - q_org[0]), (float)(o.y - q_org[1]), (float)(o.z - q_org[2])};   // RN32 of the f64 difference
+    bool ok = true;
+    float c_max = 0.0f, d_max = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float inv = 1.0f / dv[a];           // correctly rounded (no fast-math)
+        r.inv[a] = q_delta[a] * inv;              // s
+        r.oi[a] = ov[a] * inv;                    // c
+        const float ai = fabsf(inv), ac = fabsf(r.oi[a]), as = fabsf(r.inv[a]);
+        // every product in the normal range (a grid without extent on an axis has delta = 0 exactly: s = 0 is then exact)
+        ok = ok && ai >= 1e-30f && ai <= 1e15f && ac <= 1e15f && (q_delta[a] == 0.0f || (as >= 1e-30f && as <= 1e30f));
+        c_max = fmaxf(c_max, ac);
+        d_max = fmaxf(d_max, as);
+    }
+    const float t = (float)tmin;
+    ok = ok && t >= 1e-30f && t <= 1e15f && tmin <= tmax;
+    r.tmin32 = t;
+    r.K = ok ? fmaf(c_max, 16.2f * 0x1.0p-24f, fmaf(d_max, 1.001f, 2e-30f)) : __builtin_inff();
+    rayf32_set_tmax(r, tmax);
+}
+// Returns whether the answer is certain; `hit` is the answer when it is.  p: the six planes as f32 (Q16 = false) or
+// the six grid steps converted to f32 (Q16 = true), in the record's order.
+template <bool Q16>
+__device__ __forceinline__ bool box_hit_tier1(const float p[6], const RayF32& r, bool& hit) {
     const float t0x = fmaf(p[0], r.inv[0], -r.oi[0]), t1x = fmaf(p[1], r.inv[0], -r.oi[0]);
     const float t0y = fmaf(p[2], r.inv[1], -r.oi[1]), t1y = fmaf(p[3], r.inv[1], -r.oi[1]);
     const float t0z = fmaf(p[4], r.inv[2], -r.oi[2]), t1z = fmaf(p[5], r.inv[2], -r.oi[2]);
@@ -482,11 +536,13 @@ __device__ __forceinline__ bool box_hit_f32(const float p[6], const RayF32& r, b
     const float lo = fmaxf(fmaxf(nx, ny), nz), hi = fminf(fminf(fx, fy), fz);
     const float mn = fminf(fminf(nx, ny), nz), mx = fmaxf(fmaxf(fx, fy), fz);
     const float M = fmaxf(fmaxf(-mn, mx), r.tg);
-    const float T = fmaf(M, 12.2f * 0x1.0p-24f, r.K);
+    const float T = fmaf(M, Q16 ? TIER_Q16_COEF : TIER_F32_COEF, r.K);
     const float m = fminf(hi, r.tmax32) - fmaxf(lo, r.tmin32);   // = min(s1, s2, s3, tmax32 - tmin32), one subtraction
     hit = m > T;
     return fabsf(m) > T;   // T >= 0 (M >= 0: -mn or mx is; K >= 0), so this is m > T || m < -T in one comparison
 }
+
+__device__ __forceinline__ bool box_hit_f32(const float p[6], const RayF32& r, bool& hit) { return box_hit_tier1<false>(p, r, hit); }
 
 // ---------------------------------------------------------------- primitive tests
 // sphere::hit, src/geometry.rs:204-230 (the t part; the rest of Hit is completed for the winner only)

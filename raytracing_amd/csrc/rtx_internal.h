@@ -97,6 +97,7 @@ struct rtx_scene {
     rtx::DevBuf<rtx::DSphere> spheres;
     rtx::DevBuf<rtx::DPlanar> planars;
     rtx::DevBuf<rtx::DNode32> nodes32;
+    rtx::DevBuf<rtx::DNode16> nodes16;
     rtx::DevBuf<rtx::DBox64> boxes64;
     rtx::DevBuf<uint32_t> rec_user_id;
     rtx::DevBuf<rtx::DShadeRec> shade_recs;

@@ -548,7 +548,8 @@ struct WorkCounters {
     unsigned long long nodes = 0, spheres = 0, planars = 0, fallbacks = 0;
 };
 
-template <bool COUNT, bool LDS_NODES, bool SHARED, bool BATCH>
+// REC16 (trees in global memory only): the 16-byte quantised records (DNode16) instead of the 32-byte f32 ones.
+template <bool COUNT, bool LDS_NODES, bool SHARED, bool BATCH, bool REC16 = false>
 __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState& rays, const DHits& hits, const TraverseWork& w, double tmin,
                                                   double tmax0, DRenderCtl* ctl, WorkCounters& wc) {
     const uint32_t lane = lane_id();
@@ -559,14 +560,17 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
     uint32_t next_p = 0;   // !SHARED: next position of the wave's own list
     const bool scene_filter = sc.filter_ok != 0u;
     constexpr bool batch_undecided = BATCH;   // a separate instance of the kernel: with both forms in one loop the common one is 3 % slower
-    const uint32_t end = sc.n_nodes * 32u;   // nodes are addressed by the byte offset of their 32-byte record
+    static_assert(!(REC16 && LDS_NODES), "the quantised records are for trees that do not fit in LDS");
+    constexpr uint32_t REC_BYTES = REC16 ? 16u : 32u, REC_SHIFT = REC16 ? 4u : 5u;
+    const uint32_t end = sc.n_nodes * REC_BYTES;   // nodes are addressed by the byte offset of their record
 
     uint32_t idx = NONE;   // ray of this lane, NONE = idle
     V3 o = v3(0, 0, 0), d = v3(1, 1, 1);
     double tmax = tmax0;   // == t of the best hit so far once there is one
     uint32_t best_leaf = NONE, node = 0;   // node: byte offset of the f32 record (index * 32)
     RayF32 rf;
-    rayf32_init(rf, o, d, tmin, tmax0);
+    if (REC16) rayq16_init(rf, o, d, tmin, tmax0, sc.q_org, sc.q_delta);
+    else rayf32_init(rf, o, d, tmin, tmax0);
     uint32_t c_nodes = 0, c_sph = 0, c_pln = 0, c_fallback = 0;
     bool pending = false;    // standing on a leaf whose box was hit, surface not tested yet
     uint32_t leaf = NONE;
@@ -607,7 +611,8 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
                 tmax = tmax0;
                 best_leaf = NONE;
                 node = 0;
-                rayf32_init(rf, o, d, tmin, tmax0);
+                if (REC16) rayq16_init(rf, o, d, tmin, tmax0, sc.q_org, sc.q_delta);
+                else rayf32_init(rf, o, d, tmin, tmax0);
             }
         }
 
@@ -622,36 +627,53 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
         bool searching = idx != NONE && node < end;
         bool undecided = false;
         while (searching) {       // lanes leave the loop one by one; the wave stays until all have left
-            uint4 n0, n1;
-            if (LDS_NODES) {
-                const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + node);
-                n0 = np[0];
-                n1 = np[1];
+            // the record: six planes (f32, or grid steps as f32), whether it is a leaf, its surface code if so,
+            // and the byte offset of the record that follows its subtree
+            float planes[6];
+            bool is_leaf;
+            uint32_t leaf_code, succ;
+            if (REC16) {
+                const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes16) + node);
+                planes[0] = (float)(r.x & 0xFFFFu); planes[1] = (float)(r.x >> 16);
+                planes[2] = (float)(r.y & 0xFFFFu); planes[3] = (float)(r.y >> 16);
+                planes[4] = (float)(r.z & 0xFFFFu); planes[5] = (float)(r.z >> 16);
+                is_leaf = r.w < NODE16_INTERNAL;
+                leaf_code = r.w;
+                succ = is_leaf ? node + 16u : r.w << 4;   // the tag bits shift out; a leaf is followed by the next record
             } else {
-                const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + node);
-                n0 = np[0];
-                n1 = np[1];
+                uint4 n0, n1;
+                if (LDS_NODES) {
+                    const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + node);
+                    n0 = np[0];
+                    n1 = np[1];
+                } else {
+                    const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + node);
+                    n0 = np[0];
+                    n1 = np[1];
+                }
+                planes[0] = __uint_as_float(n0.x); planes[1] = __uint_as_float(n0.y); planes[2] = __uint_as_float(n0.z);
+                planes[3] = __uint_as_float(n0.w); planes[4] = __uint_as_float(n1.x); planes[5] = __uint_as_float(n1.y);
+                is_leaf = n1.w != NONE;
+                leaf_code = n1.w;
+                succ = n1.z;
             }
             if (COUNT) ++c_nodes;
-            const float planes[6] = {__uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z),
-                                     __uint_as_float(n0.w), __uint_as_float(n1.x), __uint_as_float(n1.y)};
             bool hit;
-            bool decided = box_hit_f32(planes, rf, hit);
-            const bool is_leaf = n1.w != NONE;
+            bool decided = box_hit_tier1<REC16>(planes, rf, hit);
             // The lanes that start waiting in this step are counted from the comparisons' own masks (the ballot of a
             // combined flag costs two vector instructions per step): f32 says hit (that implies decided) on a leaf ...
             uint32_t n_new = (uint32_t)__popcll(ballot64(hit) & ballot64(is_leaf));
             if (batch_undecided) n_new += (uint32_t)__popcll(ballot64(true) & ~ballot64(decided));   // ... or undecided
             if (!decided && !batch_undecided) {   // few such tests in this scene: the exact box, f64 filter, then the division form, here
-                const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> 5));
+                const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> REC_SHIFT));
                 const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
                 if (COUNT) ++c_fallback;
                 hit = tier2_box(q0, q1, q2, o, d, tmin, tmax, scene_filter);
                 decided = true;   // (a leaf found here waits uncounted: counting inside this branch would make the count per-lane)
             }
             const bool found = decided && hit && is_leaf;
-            if (decided) node = (hit && !is_leaf) ? node + 32u : n1.z;   // links are byte offsets; a leaf's successor is its miss link as well
-            leaf = n1.w;   // only read once the lane waits on this leaf; a lane that walks on overwrites it
+            if (decided) node = (hit && !is_leaf) ? node + REC_BYTES : succ;   // links are byte offsets; a leaf's successor is its miss link as well
+            leaf = leaf_code;   // only read once the lane waits on this leaf; a lane that walks on overwrites it
             pending = found;
             undecided = !decided;
             n_pending += n_new;
@@ -666,16 +688,27 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
 #ifdef RTX_PROFILE_PHASES
             ++pt_fb_iters;
 #endif
-            const uint4 n1 = LDS_NODES ? reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + node)[1]
-                                       : reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + node)[1];
-            const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> 5));
+            bool is_leaf;
+            uint32_t leaf_code, succ;
+            if (REC16) {
+                const uint32_t link = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes16) + node)->w;
+                is_leaf = link < NODE16_INTERNAL;
+                leaf_code = link;
+                succ = is_leaf ? node + 16u : link << 4;
+            } else {
+                const uint4 n1 = LDS_NODES ? reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + node)[1]
+                                           : reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + node)[1];
+                is_leaf = n1.w != NONE;
+                leaf_code = n1.w;
+                succ = n1.z;
+            }
+            const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> REC_SHIFT));
             const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
             if (COUNT) ++c_fallback;
             const bool hit = tier2_box(q0, q1, q2, o, d, tmin, tmax, scene_filter);
-            const bool is_leaf = n1.w != NONE;
             pending = hit && is_leaf;
-            node = (hit && !is_leaf) ? node + 32u : n1.z;
-            leaf = pending ? n1.w : leaf;
+            node = (hit && !is_leaf) ? node + REC_BYTES : succ;
+            leaf = pending ? leaf_code : leaf;
             undecided = false;
         }
         PT(pt_p1);
@@ -752,7 +785,7 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
     }
 }
 
-template <bool COUNT, bool LDS_NODES, bool BATCH>
+template <bool COUNT, bool LDS_NODES, bool BATCH, bool REC16 = false>
 __global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_traverse_f32(DScene sc, DState rays, DHits hits, DPool pool,
                                                                                        double tmin, double tmax0, DRenderCtl* ctl,
                                                                                        uint32_t lds_surfaces) {
@@ -802,7 +835,7 @@ __global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_trav
     w.first_pool = first_pool;
     w.sub_capacity = pool.sub_capacity;
     WorkCounters wc;
-    traverse_f32_wave<COUNT, LDS_NODES, true, BATCH>(sc, rays, hits, w, tmin, tmax0, ctl, wc);
+    traverse_f32_wave<COUNT, LDS_NODES, true, BATCH, REC16>(sc, rays, hits, w, tmin, tmax0, ctl, wc);
     if (COUNT && ctl) {
         atomicAdd(&ctl->node_visits, wc.nodes);
         atomicAdd(&ctl->sphere_tests, wc.spheres);
@@ -1096,6 +1129,7 @@ __device__ __forceinline__ DScene uniform_scene(const DScene& s) {
     DScene u = s;
     u.nodes = uniform_p(s.nodes); u.spheres = uniform_p(s.spheres); u.planars = uniform_p(s.planars);
     u.nodes32 = uniform_p(s.nodes32);
+    u.nodes16 = uniform_p(s.nodes16);
     u.boxes64 = uniform_p(s.boxes64); u.shade_recs = uniform_p(s.shade_recs); u.rec_user_id = uniform_p(s.rec_user_id);
     u.n_nodes = uniform32(s.n_nodes); u.filter_ok = uniform32(s.filter_ok); u.batch_undecided = uniform32(s.batch_undecided); u.pend_at = uniform32(s.pend_at); u.refill_at = uniform32(s.refill_at);
     u.n_spheres = uniform32(s.n_spheres); u.n_planars = uniform32(s.n_planars);
@@ -1109,7 +1143,7 @@ __device__ RTX_PHASE_INLINE void phase_generate(const DRenderParams* pp, uint32_
     first = uniform64(first);
     generate_wave<false>(P->cam, uniform_state(P->st[parity]), slot0, first, got, uniform64(P->seed), uniform32(P->spp_begin));
 }
-template <bool COUNT, bool LDS_NODES, bool BATCH>
+template <bool COUNT, bool LDS_NODES, bool BATCH, bool REC16>
 __device__ RTX_PHASE_INLINE void phase_traverse(const DRenderParams* pp, uint32_t parity, uint32_t base, uint32_t count, WorkCounters* wc) {
     extern __shared__ uint4 lds_nodes[];
     const DRenderParams* P = uniform_ptr(pp);
@@ -1122,7 +1156,7 @@ __device__ RTX_PHASE_INLINE void phase_traverse(const DRenderParams* pp, uint32_
     w.base = uniform32(base);
     w.count = uniform32(count);
     WorkCounters local;
-    traverse_f32_wave<COUNT, LDS_NODES, false, BATCH>(uniform_scene(P->sc), uniform_state(P->st[parity]), uniform_hits(P->hits), w,
+    traverse_f32_wave<COUNT, LDS_NODES, false, BATCH, REC16>(uniform_scene(P->sc), uniform_state(P->st[parity]), uniform_hits(P->hits), w,
                                                __longlong_as_double((long long)uniform64((unsigned long long)__double_as_longlong(P->tmin))),
                                                __longlong_as_double((long long)uniform64((unsigned long long)__double_as_longlong(P->tmax0))), uniform_p(P->ctl), local);
     if (COUNT) {
@@ -1152,7 +1186,7 @@ __device__ RTX_PHASE_INLINE uint32_t phase_shade(const DRenderParams* pp, uint32
 // The fifth wave is given up for surface tests without a trip to memory and for the registers that let the shade phase read a whole
 // row ahead: +1.9 % on the headline frame (42.3 against 43.1 ms per 100 spp).
 constexpr uint32_t WIDE_BLOCK = 1024;
-template <bool COUNT, bool LDS_NODES, bool BATCH, bool WIDE = false>
+template <bool COUNT, bool LDS_NODES, bool BATCH, bool WIDE = false, bool REC16 = false>
 __global__ __launch_bounds__(WIDE ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK, WIDE ? 4 : RTX_PERSISTENT_WAVES) void k_render_persistent(const DRenderParams* P) {
     extern __shared__ uint4 lds_nodes[];
     if (LDS_NODES) {
@@ -1214,7 +1248,7 @@ __global__ __launch_bounds__(WIDE ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK, WIDE ? 4 
         if (count == 0u) break;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         PP(pp_gen);
-        phase_traverse<COUNT, LDS_NODES, BATCH>(P, parity, base, count, &wc);
+        phase_traverse<COUNT, LDS_NODES, BATCH, REC16>(P, parity, base, count, &wc);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         PP(pp_trav);
         n_rays += count;
@@ -1353,6 +1387,13 @@ void launch_traverse_f32(const DScene& sc, const DState& rays, const DHits& hits
     } else {
         dim3 g(grid_for_pool(pool.n_sub)), b(BLOCK);
         const bool batch = sc.batch_undecided != 0u;
+        if (sc.use16 && sc.nodes16) {   // the half-size records of a large tree
+            if (count_work && batch) hipLaunchKernelGGL((k_traverse_f32<true, false, true, true>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
+            else if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, false, false, true>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
+            else if (batch) hipLaunchKernelGGL((k_traverse_f32<false, false, true, true>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
+            else hipLaunchKernelGGL((k_traverse_f32<false, false, false, true>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
+            return;
+        }
         if (count_work && batch) hipLaunchKernelGGL((k_traverse_f32<true, false, true>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
         else if (count_work) hipLaunchKernelGGL((k_traverse_f32<true, false, false>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
         else if (batch) hipLaunchKernelGGL((k_traverse_f32<false, false, true>), g, b, 0, s, sc, rays, hits, pool, tmin, tmax, ctl, 0u);
@@ -1378,6 +1419,7 @@ uint32_t persistent_waves_per_cu(const DScene& sc, uint32_t lds_mode, bool recs)
     const uint32_t block = lds_mode >= 3u ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK;
     hipError_t e = lds_mode >= 3u ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, true, false, true>, block, lds)
                    : lds_mode  ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, true, false>, block, lds)
+                   : (sc.use16 && sc.nodes16) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, false, false, false, true>, block, lds)
                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_persistent<false, false, false>, block, lds);
     if (e != hipSuccess || nb < 1) nb = 1;
     return (uint32_t)nb * (block / 64);   // waves
@@ -1399,6 +1441,11 @@ void launch_render_persistent(const DRenderParams* params, const DRenderParams& 
         else if (count_work) hipLaunchKernelGGL((k_render_persistent<true, true, false>), g, b, lds, s, params);
         else if (batch) hipLaunchKernelGGL((k_render_persistent<false, true, true>), g, b, lds, s, params);
         else hipLaunchKernelGGL((k_render_persistent<false, true, false>), g, b, lds, s, params);
+    } else if (host_params.sc.use16 && host_params.sc.nodes16) {
+        if (count_work && batch) hipLaunchKernelGGL((k_render_persistent<true, false, true, false, true>), g, b, 0, s, params);
+        else if (count_work) hipLaunchKernelGGL((k_render_persistent<true, false, false, false, true>), g, b, 0, s, params);
+        else if (batch) hipLaunchKernelGGL((k_render_persistent<false, false, true, false, true>), g, b, 0, s, params);
+        else hipLaunchKernelGGL((k_render_persistent<false, false, false, false, true>), g, b, 0, s, params);
     } else {
         if (count_work && batch) hipLaunchKernelGGL((k_render_persistent<true, false, true>), g, b, 0, s, params);
         else if (count_work) hipLaunchKernelGGL((k_render_persistent<true, false, false>), g, b, 0, s, params);

@@ -71,6 +71,72 @@ def test_million_surface_scene_against_the_oracle(rt, oracle, kind):
     orc.close()
 
 
+@pytest.mark.parametrize("name", ["cover_spheres", "cornell_box", "quads", "demo_spheres", "soup_spheres_30k", "soup_triangles_30k"])
+def test_quantised_node_records_give_the_reference_answer(rt, oracle, name, monkeypatch):
+    """Large trees are walked through 16-byte records whose box planes are 16-bit steps of a per-scene grid; a visit
+    whose margin is inside the grid's resolution goes to the exact box instead.  Forced here onto small scenes too,
+    where the grid is coarse against the boxes (cover_spheres: 0.03 per step under spheres of radius 0.2; the Cornell
+    box's walls are a hundredth of a step thick), so the exact tiers take a large share: ids, distances and the numbers of box
+    and surface tests must still be the oracle's, through trace_closest and through both render paths."""
+    import torch
+
+    monkeypatch.setenv("RTX_NODE16", "1")
+    monkeypatch.setenv("RTX_LDS_WIDE_BYTES", "0")
+    if name.startswith("soup_"):
+        surfaces, cam = S.synthetic_soup(n=30_000, kind=name.split("_")[1], seed=5, image_width=256, samples_per_pixel=1)
+        cam = dict(cam, max_depth=5)
+    else:
+        surfaces, cam = S.EXAMPLES[name]()
+        cam = dict(cam, image_width=min(cam["image_width"], 256))
+    dev, orc = rt.Scene(rt.HostBVH(surfaces)), oracle.Scene(surfaces)
+    icam, ocam = rt.camera_initialize(cam), oracle.camera_initialize(cam)
+    org, d = rt.primary_rays(icam, 3, 1)
+    rng = np.random.default_rng(5)
+    fallbacks = visits = 0
+    for bounce in range(3):
+        ids, t, st = dev.trace_closest(org, d, flags=rt.FLAG_COUNT_WORK | rt.FLAG_NO_LDS)
+        wid, wt, ctr = orc.trace_closest(org, d)
+        assert np.array_equal(ids, wid) and np.array_equal(bits(t), bits(np.where(wid == NONE, np.inf, wt))), f"bounce {bounce}"
+        assert [st.node_visits, st.sphere_tests, st.planar_tests] == [ctr.node_visits, ctr.sphere_tests, ctr.planar_tests]
+        fallbacks += st.box_fallbacks
+        visits += st.node_visits
+        hit = ids != NONE
+        if not hit.any():
+            break
+        org = org[hit] + d[hit] * t[hit, None]
+        d = rng.normal(size=org.shape) * rng.choice([1e-3, 1.0, 50.0], size=(len(org), 1))
+    if name in ("cover_spheres", "cornell_box"):
+        assert fallbacks > 0.05 * visits      # the coarse grid does send these scenes to the exact tiers
+    if name.startswith("soup_"):
+        assert fallbacks < 0.05 * visits      # ... and a scene of the intended kind mostly not
+    for persistent in ("1", "0"):
+        monkeypatch.setenv("RTX_PERSISTENT", persistent)
+        acc = torch.zeros(icam.image_height, icam.image_width, 3, dtype=torch.float64, device="cuda")
+        st = dev.render_accumulate(icam, 11, 2, 1, acc.data_ptr(), torch.cuda.current_stream().cuda_stream, rt.FLAG_COUNT_WORK | rt.FLAG_NO_LDS)
+        want, ctr = orc.render(ocam, 11, 2, 1, iterative=True)
+        assert [st.rays, st.node_visits, st.sphere_tests, st.planar_tests] == [ctr.rays, ctr.node_visits, ctr.sphere_tests, ctr.planar_tests]
+        assert np.array_equal(bits(acc.cpu().numpy() + 0.0), bits(want + 0.0))
+
+
+def test_quantised_records_degenerate_rays(rt, oracle, monkeypatch):
+    """Zero, tiny, huge and non-finite direction components and origins far outside the grid."""
+    monkeypatch.setenv("RTX_NODE16", "1")
+    surfaces, cam = S.synthetic_soup(n=20_000, kind="spheres", seed=9, image_width=64)
+    dev, orc = rt.Scene(rt.HostBVH(surfaces)), oracle.Scene(surfaces)
+    rng = np.random.default_rng(2)
+    n = 30000
+    org = rng.uniform(-60, 60, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d[rng.random((n, 3)) < 0.3] = 0.0
+    org[: n // 4] = np.round(org[: n // 4])
+    org[n // 4: n // 4 + 500] *= 1e6                       # far outside the grid
+    d[-8:] = [[np.inf, 1, 1], [np.nan, 0, 1], [1e-320, 1, 0], [1e305, 1, 1], [0, 0, 0], [-0.0, 1, 0], [1, -np.inf, 0], [1e-310, 1e-310, 1e-310]]
+    wid, wt, _ = orc.trace_closest(org, d)
+    ids, t, _ = dev.trace_closest(org, d, flags=rt.FLAG_NO_LDS)
+    assert np.array_equal(ids, wid) and np.array_equal(bits(t), bits(np.where(wid == NONE, np.inf, wt)))
+    assert (wid != NONE).sum() > 1000
+
+
 def test_uv_gradient_on_spheres(rt, oracle):
     """Sphere u,v come from acos(-p.y) and atan2(-p.z, p.x) of the world-space point (src/geometry.rs:236-240) and
     feed Material::emitted of UVGradient (src/material.rs:46-52).  The device's acos / atan2 are accurate to a few
