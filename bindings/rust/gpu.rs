@@ -266,6 +266,34 @@ impl InitializedCamera {
     }
 }
 
+impl InitializedCamera {
+    /// The same frame on `n_gpus` GPUs of this node from this one process: samples per pixel split over the devices,
+    /// one RCCL reduce onto device 0 (rtx_multi_render), then the P3 text of the summed image from device 0.
+    pub fn render_multi_gpu(&self, world: &BVH, seed: u64, n_gpus: i32) -> Result<sys::rtx_multi_stats, Box<dyn Error>> {
+        let flat = world.flatten();
+        let cam = self.to_ffi();
+        let mut multi = std::ptr::null_mut();
+        check(unsafe { sys::rtx_multi_create(&flat.desc(), n_gpus, &mut multi) })?;   // scene on every device + communicator: once
+        let mut stats = sys::rtx_multi_stats::default();
+        let mut rc = unsafe { sys::rtx_multi_render(multi, &cam, seed, 0, std::ptr::null_mut(), &mut stats) };
+        let mut text = Vec::new();
+        let mut len = 0u64;
+        if rc == 0 {
+            let capacity = unsafe { sys::rtx_ppm_text_bound(cam.image_width, cam.image_height) };
+            text.resize(capacity as usize, 0u8);
+            // the image is device-0 memory; the main thread's current device is 0 unless the caller changed it
+            rc = unsafe {
+                sys::rtx_ppm_text(sys::rtx_multi_image(multi), cam.image_width, cam.image_height, text.as_mut_ptr() as *mut _, capacity, &mut len,
+                                  std::ptr::null_mut())
+            };
+        }
+        unsafe { sys::rtx_multi_destroy(multi) };
+        check(rc)?;
+        std::io::stdout().lock().write_all(&text[..len as usize])?;
+        Ok(stats)
+    }
+}
+
 impl RenderRunner {
     /// `run` (src/runner.rs:23-41) with the sample loop on the GPU.  The reference seeds its RNG from the OS;
     /// here the seed of the counter-based streams is drawn the same way, so two runs differ as they do there.

@@ -152,6 +152,12 @@ int rtx_multi_render(rtx_multi* m, const rtx_camera* cam, uint64_t seed, uint32_
     const uint32_t world = (uint32_t)m->ranks.size();
     const size_t nval = 3ull * cam->image_width * cam->image_height;
     Rccl& nc = rccl();
+    int entry_device = 0;   // the calling thread's current device is the same after the call as before it
+    (void)hipGetDevice(&entry_device);
+    struct Restore {
+        int device;
+        ~Restore() { (void)hipSetDevice(device); }
+    } restore{entry_device};
 
     // set-up that is not part of the frame: accumulation buffers of the right size on every device
     for (Rank& r : m->ranks) {
@@ -196,7 +202,6 @@ int rtx_multi_render(rtx_multi* m, const rtx_camera* cam, uint64_t seed, uint32_
     // A device that failed would leave the others waiting in the collective for ever: the reduce starts only when all have rendered.
     for (uint32_t g = 0; g < world; ++g)
         if (res[g].rc != RTX_OK) {
-            (void)hipSetDevice(m->prior_device);
             return api_fail(res[g].rc, "rtx_multi_render: device " + std::to_string(m->ranks[g].device) + ": " + res[g].msg);
         }
     // Phase 2, the one collective of the frame: every device's rank of the sum onto device 0, as one group.
@@ -211,7 +216,6 @@ int rtx_multi_render(rtx_multi* m, const rtx_camera* cam, uint64_t seed, uint32_
     const ncclResult_t e_end = nc.GroupEnd();
     if (e == ncclSuccess) e = e_end;
     if (e != ncclSuccess) {
-        (void)hipSetDevice(m->prior_device);
         return api_fail(RTX_ERR_RCCL, std::string("rtx_multi_render: ncclReduce: ") + nc.GetErrorString(e));
     }
     HIP_TRY(hipSetDevice(m->ranks[0].device));
@@ -239,7 +243,6 @@ int rtx_multi_render(rtx_multi* m, const rtx_camera* cam, uint64_t seed, uint32_
         }
     }
     if (out_rgb) HIP_TRY(hipMemcpy(out_rgb, m->ranks[0].accum.p, nval * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipSetDevice(m->prior_device);
     return RTX_OK;
 }
 
