@@ -309,6 +309,53 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
         if (!q16_ok) nodes16.clear();
     }
 
+    // Many box tests of such a scene are left to the f64 tiers: the walk then collects those lanes and resolves
+    // them together instead of one by one inside its loop (RTX_BATCH_F64_BOXES=0/1 overrides the choice).
+    const uint32_t batch_undecided = env_u32("RTX_BATCH_F64_BOXES", (uint64_t)thin_nodes * 20u >= n ? 1u : 0u, true);
+    if (batch_undecided) {
+        // In that form of the walk a node is flagged (bit 0 of its link, whose low five bits are otherwise zero) when every
+        // surface below it lies inside the node's box with room to spare.  For such a node "a surface below is hit inside the
+        // interval" implies "the node's box test passes", so where the f32 tier cannot decide the box the walk may go on as if
+        // it had passed: if the reference culls the node, nothing below it can be hit, and the outcome is the same.  Room to
+        // spare: every corner of every quad and triangle below at least 1e-9 of the largest box coordinate, and 1e-6 of the
+        // surface's own extent, away from all six faces -- far more than the rounding of either test; the reference's padded
+        // boxes (src/aabb.rs:78-87) leave 1e-4 or a whole extent.  A sphere touches its box, so nodes above spheres never qualify.
+        struct Corners { double lo[3], hi[3], ext[3]; bool ok; };
+        std::vector<Corners> cb(n);
+        for (uint32_t i = n; i-- > 0u;) {
+            Corners& c = cb[i];
+            const uint32_t prim = desc->node_prim[i];
+            if (prim != RTX_NONE) {
+                c.ok = prims[prim].kind != RTX_SPHERE;
+                if (c.ok) {
+                    const DPlanar& g = planars[prims[prim].slot];
+                    const bool quad = prims[prim].kind == RTX_QUAD;
+                    for (int a = 0; a < 3; ++a) {
+                        const double p0 = g.q[a], p1 = g.q[a] + g.u[a], p2 = g.q[a] + g.v[a], p3 = quad ? g.q[a] + g.u[a] + g.v[a] : p0;
+                        c.lo[a] = std::fmin(std::fmin(p0, p1), std::fmin(p2, p3));
+                        c.hi[a] = std::fmax(std::fmax(p0, p1), std::fmax(p2, p3));
+                        c.ext[a] = std::fabs(g.u[a]) + std::fabs(g.v[a]);
+                    }
+                }
+            } else {
+                const Corners &l = cb[i + 1], &r = cb[desc->node_right[i]];
+                c.ok = l.ok && r.ok;
+                for (int a = 0; a < 3; ++a) {
+                    c.lo[a] = std::fmin(l.lo[a], r.lo[a]);
+                    c.hi[a] = std::fmax(l.hi[a], r.hi[a]);
+                    c.ext[a] = std::fmax(l.ext[a], r.ext[a]);
+                }
+            }
+            bool inside = c.ok;
+            for (int a = 0; a < 3 && inside; ++a) {
+                const double big = std::fmax(std::fabs(nodes[i].bmin[a]), std::fabs(nodes[i].bmax[a]));
+                const double room = std::fmax(1e-9 * big, 1e-6 * c.ext[a]) + 1e-300;
+                inside = c.lo[a] - nodes[i].bmin[a] >= room && nodes[i].bmax[a] - c.hi[a] >= room;
+            }
+            if (inside) nodes32[i].miss |= 1u;
+        }
+    }
+
     rtx_scene* sc = new rtx_scene();
     auto bail = [&](int code) {
         delete sc;
@@ -339,15 +386,14 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     sc->d.planars = sc->planars.p;
     sc->d.n_nodes = n;
     sc->d.filter_ok = filter_ok ? 1u : 0u;
-    // Many box tests of such a scene are left to the f64 tiers: the walk then collects those lanes and resolves
-    // them together instead of one by one inside its loop (RTX_BATCH_F64_BOXES=0/1 overrides the choice).
-    sc->d.batch_undecided = env_u32("RTX_BATCH_F64_BOXES", (uint64_t)thin_nodes * 20u >= n ? 1u : 0u, true);
+    sc->d.batch_undecided = batch_undecided;
     // Waiting for more lanes before the surface tests run pays where those tests are the larger part of the walk:
     // scenes of quads and triangles (57 flop a test, and their tripled boxes are hit often); most where the whole scene sits in LDS
-    // (Cornell box: 40 lanes +1.8 % over 32; a 10^6-triangle tree in global memory loses 4.5 % with 40).
+    // (32 lanes; 40 was 1.8 % better on the Cornell box while undecided box tests still counted as waiting lanes, and is 4 % worse
+    // since flagged nodes no longer wait: 9633 against 10035 Mrays/s; a 10^6-triangle tree in global memory loses 4.5 % with 40).
     const size_t scene_bytes = (size_t)n * sizeof(DNode32) + spheres.size() * sizeof(DSphere) + planars.size() * sizeof(DPlanar);
     const bool planar_scene = planars.size() > spheres.size(), small_scene = scene_bytes <= 32u * 1024u;
-    sc->d.pend_at = env_u32("RTX_PEND_AT", planar_scene ? (small_scene ? 40u : 32u) : 16u);
+    sc->d.pend_at = env_u32("RTX_PEND_AT", planar_scene ? 32u : 16u);
     if (sc->d.pend_at > 64u) sc->d.pend_at = 64u;
     // Idle lanes take their next rays once 32 lanes are idle; once 16 are where the whole scene sits in LDS and the surface tests
     // dominate (Cornell box +8 %, quads +4 %; the headline scene loses 2 % with 16, a 10^6-triangle tree in global memory 5 %).

@@ -630,7 +630,7 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
             // the record: six planes (f32, or grid steps as f32), whether it is a leaf, its surface code if so,
             // and the byte offset of the record that follows its subtree
             float planes[6];
-            bool is_leaf;
+            bool is_leaf, contained = false;
             uint32_t leaf_code, succ;
             if (REC16) {
                 const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes16) + node);
@@ -655,11 +655,21 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
                 planes[3] = __uint_as_float(n0.w); planes[4] = __uint_as_float(n1.x); planes[5] = __uint_as_float(n1.y);
                 is_leaf = n1.w != NONE;
                 leaf_code = n1.w;
-                succ = n1.z;
+                succ = BATCH ? (n1.z & ~31u) : n1.z;   // scenes of the BATCH form keep a flag in the (otherwise zero) low bits of a leaf's link
+                contained = BATCH && (n1.z & 1u) != 0u;
             }
             if (COUNT) ++c_nodes;
             bool hit;
             bool decided = box_hit_tier1<REC16>(planes, rf, hit);
+            if (BATCH && !COUNT && !REC16) {
+                // A node whose surfaces all lie inside its box with a margin (flagged when the scene was created): a hit of one
+                // of them inside [tmin, tmax] implies that the box test passes, so where the f32 tier cannot decide the box the walk
+                // goes on as if it had passed.  If the reference culls the node, nothing below it is hit and the outcome is the
+                // reference's; only the numbers of box and surface tests can differ, so the counting instances do not take this path.
+                const bool assume = !decided && contained && rf.tmin32 < rf.tmax32 && rf.K <= 3.0e38f;
+                hit = hit || assume;
+                decided = decided || assume;
+            }
             // The lanes that start waiting in this step are counted from the comparisons' own masks (the ballot of a
             // combined flag costs two vector instructions per step): f32 says hit (that implies decided) on a leaf ...
             uint32_t n_new = (uint32_t)__popcll(ballot64(hit) & ballot64(is_leaf));
@@ -700,7 +710,7 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
                                            : reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + node)[1];
                 is_leaf = n1.w != NONE;
                 leaf_code = n1.w;
-                succ = n1.z;
+                succ = BATCH ? (n1.z & ~31u) : n1.z;
             }
             const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> REC_SHIFT));
             const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
