@@ -71,8 +71,9 @@ def test_million_surface_scene_against_the_oracle(rt, oracle, kind):
     orc.close()
 
 
-@pytest.mark.parametrize("name", ["cover_spheres", "cornell_box", "quads", "demo_spheres", "soup_spheres_30k", "soup_triangles_30k"])
-def test_quantised_node_records_give_the_reference_answer(rt, oracle, name, monkeypatch):
+@pytest.mark.parametrize("name,batch", [("cover_spheres", "1"), ("cover_spheres", "0"), ("cornell_box", "1"), ("quads", "0"), ("demo_spheres", "1"),
+                                        ("soup_spheres_30k", "1"), ("soup_spheres_30k", "0"), ("soup_triangles_30k", "1"), ("soup_triangles_30k", "0")])
+def test_quantised_node_records_give_the_reference_answer(rt, oracle, name, batch, monkeypatch):
     """Large trees are walked through 16-byte records whose box planes are 16-bit steps of a per-scene grid; a visit
     whose margin is inside the grid's resolution goes to the exact box instead.  Forced here onto small scenes too,
     where the grid is coarse against the boxes (cover_spheres: 0.03 per step under spheres of radius 0.2; the Cornell
@@ -81,6 +82,7 @@ def test_quantised_node_records_give_the_reference_answer(rt, oracle, name, monk
     import torch
 
     monkeypatch.setenv("RTX_NODE16", "1")
+    monkeypatch.setenv("RTX_BATCH_F64_BOXES", batch)   # undecided boxes resolved for all waiting lanes together (the default with these records) or in the loop
     monkeypatch.setenv("RTX_LDS_WIDE_BYTES", "0")
     if name.startswith("soup_"):
         surfaces, cam = S.synthetic_soup(n=30_000, kind=name.split("_")[1], seed=5, image_width=256, samples_per_pixel=1)
