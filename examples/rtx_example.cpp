@@ -5,7 +5,7 @@
 //
 //   rtx_example <name> [--width W] [--spp N] [--depth D] [--seed S] [--scene-seed S]
 //               [--partition bisect|midpoint|sah-equal:<buckets>|sah-per-surface]
-//               [--build host|device] [-o file.ppm]
+//               [--build host|device] [--gpus N] [-o file.ppm]
 //   rtx_example --list
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +20,7 @@ static int usage(const char* msg) {
     if (msg) std::fprintf(stderr, "rtx_example: %s\n", msg);
     std::fprintf(stderr,
                  "usage: rtx_example <name> [--width W] [--spp N] [--depth D] [--seed S] [--scene-seed S]\n"
-                 "                   [--partition bisect|midpoint|sah-equal:<buckets>|sah-per-surface] [--build host|device] [-o file.ppm]\n"
+                 "                   [--partition bisect|midpoint|sah-equal:<buckets>|sah-per-surface] [--build host|device] [--gpus N] [-o file.ppm]\n"
                  "       rtx_example --list\n");
     return 2;
 }
@@ -46,6 +46,7 @@ int main(int argc, char** argv) {
         else if (a == "--seed" && (v = value())) runner.seed = std::strtoull(v, nullptr, 0);
         else if (a == "--scene-seed" && (v = value())) scene_seed = std::strtoull(v, nullptr, 0);
         else if (a == "-o" && (v = value())) out_path = v;
+        else if (a == "--gpus" && (v = value())) runner.n_gpus = (int)std::atol(v);
         else if (a == "--build" && (v = value())) {
             if (std::strcmp(v, "device") == 0) runner.build_on_device = true;
             else if (std::strcmp(v, "host") != 0) return usage("--build takes host or device");

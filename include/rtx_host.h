@@ -92,6 +92,13 @@ int rth_run(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buck
 int rth_run_device_build(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, const rtx_camera_config* cfg,
                          uint64_t seed, const char* ppm_path, double* out_rgb);
 
+/* rth_run on n_gpus GPUs of this node from this process (RenderRunner with n_gpus set): the samples per pixel are
+ * split over the devices and summed with one RCCL reduce (rtx_multi_create / rtx_multi_render of rtx.h).  n_gpus = 1
+ * is rth_run.  The reference has no multi-device path; this is what its RenderRunner::run (src/runner.rs:23-41)
+ * calls when the host has several GPUs. */
+int rth_run_multi(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, const rtx_camera_config* cfg,
+                  uint64_t seed, int n_gpus, const char* ppm_path, double* out_rgb);
+
 #ifdef __cplusplus
 }
 #endif

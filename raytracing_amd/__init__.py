@@ -120,7 +120,7 @@ ABI_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_trace_closest", "rtx_trace_closest_device",
     "rtx_primary_rays", "rtx_render_accumulate", "rtx_scale", "rtx_quantize", "rtx_render", "rtx_selftest_math",
     "rtx_selftest_rng", "rtx_bvh_build", "rtx_multi_create", "rtx_multi_destroy", "rtx_multi_render", "rtx_multi_image", "rtx_render_multi", "rtx_ppm_text_bound", "rtx_ppm_text", "rtx_render_ppm",
-    "rth_last_error", "rth_bvh_build", "rth_bvh_build_device", "rth_run_device_build", "rth_example", "rth_bvh_desc", "rth_bvh_destroy", "rth_camera_initialize", "rth_run",
+    "rth_last_error", "rth_bvh_build", "rth_bvh_build_device", "rth_run_device_build", "rth_example", "rth_bvh_desc", "rth_bvh_destroy", "rth_camera_initialize", "rth_run", "rth_run_multi",
 ]
 
 _lib.rtx_last_error.restype = C.c_char_p
@@ -159,6 +159,7 @@ _lib.rth_bvh_desc.restype = None
 _lib.rth_bvh_destroy.argtypes = [C.c_void_p]
 _lib.rth_bvh_destroy.restype = None
 _lib.rth_camera_initialize.argtypes = [_p(CameraConfig), _p(Camera)]
+_lib.rth_run_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, _p(CameraConfig), C.c_uint64, C.c_int, C.c_char_p, _dp]
 _lib.rth_run.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, _p(CameraConfig), C.c_uint64, C.c_char_p, _dp]
 
 

@@ -645,6 +645,7 @@ struct RenderRunner {   // src/runner.rs:8-20
     PartitionBy partition_strategy = PartitionBy::surface_area_heuristic(SAHBucketStrategy::per_surface());
     uint64_t seed = 0;   // the reference seeds from the OS; a fixed seed makes a render repeatable
     bool build_on_device = false;   // BVH::from_slice_on_device instead of the host builder
+    int n_gpus = 1;                 // > 1: samples per pixel split over that many GPUs of this node, one RCCL reduce (rtx_multi_*)
 
     // src/runner.rs:23-41: build the BVH, render, write the P3 image to
     // `image_out` (the reference prints to stdout) and the three timers to
@@ -657,16 +658,33 @@ struct RenderRunner {   // src/runner.rs:8-20
         const auto bvh_done = clock::now();
 
         const InitializedCamera cam = camera.initialize();
-        rtx_scene* scene = nullptr;
         const rtx_scene_desc desc = world.desc();
-        if (rtx_scene_create(&desc, &scene) != RTX_OK) throw RenderError(rtx_last_error());
         std::vector<double> image(3 * (size_t)cam.image_width * cam.image_height);
         std::vector<char> text(image_out ? rtx_ppm_text_bound(cam.image_width, cam.image_height) : 0);   // src/camera.rs:129-131,155-161
         uint64_t text_len = 0;
-        rtx_stats stats;
-        const int rc = rtx_render_ppm(scene, &cam, seed, 0, image.data(), image_out ? text.data() : nullptr, text.size(), &text_len, &stats);
-        rtx_scene_destroy(scene);
-        if (rc != RTX_OK) throw RenderError(rtx_last_error());
+        rtx_stats stats{};
+        if (n_gpus > 1) {
+            // the scene on every device and the communicator once, then one frame: one host thread per device, one reduce onto device 0
+            rtx_multi* multi = nullptr;
+            if (rtx_multi_create(&desc, n_gpus, &multi) != RTX_OK) throw RenderError(rtx_last_error());
+            rtx_multi_stats ms{};
+            int rc = rtx_multi_render(multi, &cam, seed, 0, image.data(), &ms);
+            if (rc == RTX_OK && image_out)
+                rc = rtx_ppm_text(rtx_multi_image(multi), cam.image_width, cam.image_height, text.data(), text.size(), &text_len, nullptr);
+            const std::string msg = rc != RTX_OK ? rtx_last_error() : "";
+            rtx_multi_destroy(multi);
+            if (rc != RTX_OK) throw RenderError(msg);
+            stats.rays = ms.rays;
+            stats.paths = ms.paths;
+            stats.ms_total = ms.ms_frame;
+        } else {
+            rtx_scene* scene = nullptr;
+            if (rtx_scene_create(&desc, &scene) != RTX_OK) throw RenderError(rtx_last_error());
+            const int rc = rtx_render_ppm(scene, &cam, seed, 0, image.data(), image_out ? text.data() : nullptr, text.size(), &text_len, &stats);
+            const std::string msg = rc != RTX_OK ? rtx_last_error() : "";
+            rtx_scene_destroy(scene);
+            if (rc != RTX_OK) throw RenderError(msg);
+        }
         if (image_out) std::fwrite(text.data(), 1, text_len, image_out);
         const auto done = clock::now();
         if (log_out) {

@@ -159,7 +159,7 @@ int rth_example(const char* name, uint64_t scene_seed, rtx_surface* surfaces, ui
 }
 
 static int run_impl(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, const rtx_camera_config* cfg,
-                    uint64_t seed, const char* ppm_path, double* out_rgb, bool build_on_device) {
+                    uint64_t seed, const char* ppm_path, double* out_rgb, bool build_on_device, int n_gpus = 1) {
     if (!cfg || (n && !surfaces)) {
         g_err = "rth_run: null argument";
         return RTX_ERR_BAD_ARG;
@@ -171,6 +171,7 @@ static int run_impl(const rtx_surface* surfaces, uint32_t n, int strategy, uint3
         runner.partition_strategy = to_partition(strategy, buckets);
         runner.seed = seed;
         runner.build_on_device = build_on_device;
+        runner.n_gpus = n_gpus;
         if (ppm_path) {
             f = std::fopen(ppm_path, "wb");
             if (!f) throw RenderError(std::string("cannot open ") + ppm_path);
@@ -198,6 +199,15 @@ int rth_run(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buck
 int rth_run_device_build(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, const rtx_camera_config* cfg,
                          uint64_t seed, const char* ppm_path, double* out_rgb) {
     return run_impl(surfaces, n, strategy, buckets, cfg, seed, ppm_path, out_rgb, true);
+}
+
+int rth_run_multi(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, const rtx_camera_config* cfg,
+                  uint64_t seed, int n_gpus, const char* ppm_path, double* out_rgb) {
+    if (n_gpus < 1) {
+        g_err = "rth_run_multi: n_gpus must be at least 1";
+        return RTX_ERR_BAD_ARG;
+    }
+    return run_impl(surfaces, n, strategy, buckets, cfg, seed, ppm_path, out_rgb, false, n_gpus);
 }
 
 }  // extern "C"

@@ -46,3 +46,26 @@ def test_one_shot_render_multi_and_errors(rt):
         with pytest.raises(rt.RtxError) as e:
             rt.MultiScene(bvh, bad)
         assert e.value.code == -1
+
+
+def test_runner_on_several_gpus_writes_the_same_image(rt, oracle, tmp_path):
+    """RenderRunner with n_gpus set (rth_run_multi; bin/rtx_example --gpus N): image and P3 text as rth_run's, up to the
+    order of the f64 additions (one device: the same values through the communicator, the reduce and the scaling)."""
+    import ctypes as C
+
+    surfaces, cam = S.EXAMPLES["simple_scene"]()
+    cfg = rt.camera_config(dict(cam, samples_per_pixel=5, image_width=120))
+    icam = rt.camera_initialize(cfg)
+    single = np.zeros((icam.image_height, icam.image_width, 3))
+    multi = np.zeros_like(single)
+    ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    assert rt._lib.rth_run(surfaces.ctypes.data_as(C.c_void_p), len(surfaces), 3, 0, C.byref(cfg), 21, None, ptr(single)) == 0
+    n = min(rt.device_count(), 2)
+    path = tmp_path / "multi.ppm"
+    rc = rt._lib.rth_run_multi(surfaces.ctypes.data_as(C.c_void_p), len(surfaces), 3, 0, C.byref(cfg), 21, n, str(path).encode(), ptr(multi))
+    assert rc == 0, rt._lib.rth_last_error()
+    np.testing.assert_allclose(multi, single, rtol=1e-13, atol=0)
+    q = oracle.ppm_quantize(multi.reshape(-1, 3))
+    want = f"P3\n{icam.image_width} {icam.image_height}\n255\n" + "".join(f"{r} {g} {b}\n" for r, g, b in q.tolist())
+    assert path.read_bytes() == want.encode()
+    assert rt._lib.rth_run_multi(surfaces.ctypes.data_as(C.c_void_p), len(surfaces), 3, 0, C.byref(cfg), 21, 0, None, ptr(multi)) == -1

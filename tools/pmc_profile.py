@@ -34,7 +34,7 @@ def short(name):
 
 def main():
     out = sys.argv[1]
-    bench_args = sys.argv[2:] or ["--spp", "10", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    bench_args = sys.argv[2:] or ["--spp", "10", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pmc"]
     os.makedirs(out, exist_ok=True)
     totals, calls = {}, {}
     for i, ctrs in enumerate(PASSES):
