@@ -318,7 +318,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     // (With the quantised records 0.9 % of the visits are undecided, and resolved one by one each makes its whole wave wait for a
     // second round trip to memory in about half of the steps: batched, 10^6 spheres render 4 % faster, 949 against 912 Mrays/s.)
     const uint32_t batch_undecided = env_u32("RTX_BATCH_F64_BOXES", ((uint64_t)thin_nodes * 20u >= n || use16) ? 1u : 0u, true);
-    if (batch_undecided) {
+    if (batch_undecided && !use16) {   // (the quantised records have no room for the flag; their scenes are not the thin-box kind)
         // In that form of the walk a node is flagged (bit 0 of its link, whose low five bits are otherwise zero) when every
         // surface below it lies inside the node's box with room to spare.  For such a node "a surface below is hit inside the
         // interval" implies "the node's box test passes", so where the f32 tier cannot decide the box the walk may go on as if
