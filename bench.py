@@ -394,7 +394,7 @@ def roofline(rt, scene, n_nodes, icam, stats, begin, count, acc, stream, args):
     are bound by f64 vector arithmetic, latency and divergence: `frac` is the f64-VALU fraction, and only the ray state, hit
     records, material records and accumulation of the byte formula can reach HBM (`hbm.algorithmic`).  The 10^6-surface scenes
     walk their tree from global memory: `frac` is the byte formula with the node record this design reads (16 or 32 B per
-    visit instead of the survey's 56) over the HBM peak; the counters see more (`hbm.measured_over_algorithmic`): every
+    visit instead of the 56 B of an SoA f64 node: 48 B box + two links) over the HBM peak; the counters see more (`hbm.measured_over_algorithmic`): every
     16-byte record read that misses L2 moves a whole line."""
     cnt = scene.render_accumulate(icam, SEED, begin, min(count, 2), acc.data_ptr(), stream, rt.FLAG_COUNT_WORK)
     nv, ns, npl = cnt.node_visits / cnt.rays, cnt.sphere_tests / cnt.rays, cnt.planar_tests / cnt.rays
@@ -413,9 +413,9 @@ def roofline(rt, scene, n_nodes, icam, stats, begin, count, acc, stream, args):
     tree_on_chip = n_nodes * 32 <= 150 * 1024   # the single launch keeps trees up to 150 KB of f32 records in LDS
     if not tree_on_chip:
         # What the walk reads per node from global memory: 16-byte quantised records for trees beyond 4 MiB of f32 records
-        # (RTX_NODE16 overrides), else the 32-byte f32 records; the survey's 56 bytes are an SoA f64 node nobody reads.
+        # (RTX_NODE16 overrides), else the 32-byte f32 records; the 56 bytes of an SoA f64 node (48 B box + two links) are what nobody reads.
         rec = 16.0 if int(os.environ.get("RTX_NODE16", "1" if n_nodes * 32 > (4 << 20) else "0")) else 32.0
-        survey_gbs = gbs_all
+        soa_f64_gbs = gbs_all
         scene_bytes_per_ray = rec * nv + 32.0 * ns + 128.0 * npl
         gbs_all = (scene_bytes_per_ray + state_bytes_per_ray) * rays_per_launch / avg_launch_s / 1e9
 
@@ -462,7 +462,7 @@ def roofline(rt, scene, n_nodes, icam, stats, begin, count, acc, stream, args):
     if tree_on_chip:
         return dict({"bound": "valu_f64", "achieved": round(tf, 3), "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
                      "frac": round(tf / FP64_VECTOR_PEAK_TF, 4)}, **common)
-    common["survey_formula"] = {"bytes_per_ray": round(56.0 * nv + 32.0 * ns + 128.0 * npl + state_bytes_per_ray, 1), "GBps": round(survey_gbs, 1),
+    common["soa_f64_node_formula"] = {"bytes_per_ray": round(56.0 * nv + 32.0 * ns + 128.0 * npl + state_bytes_per_ray, 1), "GBps": round(soa_f64_gbs, 1),
                                 "note": "56 B per node visit (an SoA f64 node): more than this design reads per visit, so not a rate the memory system sees"}
     common["node_record_bytes"] = rec
     return dict({"bound": "hbm", "achieved": round(gbs_all, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_all / HBM_PEAK_GBS, 4)}, **common)
