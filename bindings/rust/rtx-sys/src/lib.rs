@@ -41,6 +41,7 @@ pub const RTX_FLAG_TIME_KERNELS: u32 = 2;
 pub const RTX_FLAG_EXACT_DIVIDE: u32 = 4;
 pub const RTX_FLAG_F64_FILTER: u32 = 8;
 pub const RTX_FLAG_NO_LDS: u32 = 16;
+pub const RTX_FLAG_NO_WAIT: u32 = 32;
 
 /// A built BVH, flattened: the pre-order node array of `BVH { tree }` (src/bvh/mod.rs:51-73) with each enum
 /// field in its own table.  Vector tables are three rows: x[0..n), y[0..n), z[0..n).

@@ -131,6 +131,7 @@ typedef struct rtx_build_stats {
 #define RTX_FLAG_EXACT_DIVIDE 4u  /* box test by six true divisions per node, exactly as src/aabb.rs:55-76 */
 #define RTX_FLAG_F64_FILTER   8u  /* skip the single-precision tier of the box test */
 #define RTX_FLAG_NO_LDS       16u /* keep the f32 node records in global memory even when they fit in LDS */
+#define RTX_FLAG_NO_WAIT      32u /* rtx_render_accumulate only: enqueue the work on `stream` and return; no stats */
 
 /* Message of the calling thread's last failed call. */
 const char* rtx_last_error(void);
@@ -207,7 +208,12 @@ int rtx_primary_rays(const rtx_camera* cam, uint64_t seed, uint32_t sample, doub
  * unscaled radiance sums into d_accum (device memory of the scene's device,
  * [H][W][3] f64, pixel = row*W+col as src/camera.rs:139).  Work is enqueued
  * on `stream` (a hipStream_t, NULL = default stream); the call returns after
- * the work has completed.  Sample s of pixel p always uses RNG stream
+ * the work has completed -- or, with RTX_FLAG_NO_WAIT, as soon as it is
+ * enqueued: d_accum is complete when `stream` has reached that point, stats
+ * is left zero, and the flag cannot be combined with the flags that need the
+ * round loop (RTX_FLAG_EXACT_DIVIDE, RTX_FLAG_F64_FILTER,
+ * RTX_FLAG_TIME_KERNELS: RTX_ERR_BAD_ARG) or RTX_FLAG_COUNT_WORK.  Calls on
+ * one scene handle must be ordered (same stream, or the caller's own events).  Sample s of pixel p always uses RNG stream
  * (seed, p, s), so any split of the sample range over calls or GPUs yields
  * the same image up to the order of floating-point addition. */
 int rtx_render_accumulate(rtx_scene* scene, const rtx_camera* cam, uint64_t seed,

@@ -38,7 +38,25 @@ uint32_t env_u32(const char* name, uint32_t dflt, bool zero_ok) {
     return (uint32_t)x;
 }
 
+int PathPool::ensure_ring() {
+    if (!h_ctl_ring) HIP_TRY(hipHostMalloc((void**)&h_ctl_ring, RING * sizeof(DRenderCtl), hipHostMallocDefault));
+    if (!h_params_ring) HIP_TRY(hipHostMalloc((void**)&h_params_ring, RING * sizeof(DRenderParams), hipHostMallocDefault));
+    for (hipEvent_t& e : ring_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return RTX_OK;
+}
+int PathPool::ring_acquire(uint32_t* slot) {
+    int rc = ensure_ring();
+    if (rc != RTX_OK) return rc;
+    *slot = ring_next++ % RING;
+    if (ring_used[*slot]) HIP_TRY(hipEventSynchronize(ring_ev[*slot]));
+    ring_used[*slot] = true;
+    return RTX_OK;
+}
+
 PathPool::~PathPool() {
+    for (hipEvent_t e : ring_ev) if (e) (void)hipEventDestroy(e);
+    if (h_ctl_ring) (void)hipHostFree(h_ctl_ring);
+    if (h_params_ring) (void)hipHostFree(h_params_ring);
     for (hipEvent_t e : kernel_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_poll) if (e) (void)hipEventDestroy(e);
     if (ev_done) (void)hipEventDestroy(ev_done);
@@ -564,6 +582,10 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     const uint64_t total = npix * spp_count;
     if (total == 0 || cam->max_depth == 0) return RTX_OK;   // ray_color returns ZERO at remaining == 0 (camera.rs:190-192)
     if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(RTX_ERR_BAD_ARG, "rtx_render_accumulate: sample index overflow");
+    const bool no_wait = (flags & RTX_FLAG_NO_WAIT) != 0;
+    if (no_wait && ((flags & (RTX_FLAG_EXACT_DIVIDE | RTX_FLAG_F64_FILTER | RTX_FLAG_TIME_KERNELS | RTX_FLAG_COUNT_WORK)) || !sc->f32_ok ||
+                    env_u32("RTX_PERSISTENT", 1, true) == 0u))
+        return fail(RTX_ERR_BAD_ARG, "rtx_render_accumulate: RTX_FLAG_NO_WAIT needs the single-launch render (no other box-test tier, no timing or counting flags, a scene within the f32 tier's range)");
     HIP_TRY(hipSetDevice(sc->device));
     hipStream_t s = (hipStream_t)stream;
 
@@ -593,9 +615,14 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         rc = pp->ensure_capacity((size_t)per_sub * n_sub);
         if (rc != RTX_OK) return rc;
         HIP_TRY(pp->params.resize(1));
-        DRenderCtl h{};
+        uint32_t slot = 0;
+        rc = pp->ring_acquire(&slot);
+        if (rc != RTX_OK) return rc;
+        DRenderCtl& h = pp->h_ctl_ring[slot];
+        h = DRenderCtl{};
         h.total_paths = total;
-        DRenderParams P{};
+        DRenderParams& P = pp->h_params_ring[slot];
+        P = DRenderParams{};
         P.sc = sc->d;
         P.cam = to_dcamera(cam);
         P.st[0] = pp->state[0];
@@ -616,10 +643,12 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         HIP_TRY(hipMemsetAsync(pp->ctl.p + 1, 0, 7 * sizeof(DRenderCtl), s));
 #endif
         HIP_TRY(hipMemcpyAsync(pp->params.p, &P, sizeof(P), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(pp->ring_ev[slot], s));   // the slot may be refilled once both uploads have executed
         HIP_TRY(hipEventRecord(sc->ev0, s));
         launch_render_persistent(pp->params.p, P, (flags & RTX_FLAG_COUNT_WORK) != 0, mode, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(sc->ev1, s));
+        if (no_wait) return RTX_OK;
         HIP_TRY(hipStreamSynchronize(s));
         if (stats) {
             float ms = 0.f;

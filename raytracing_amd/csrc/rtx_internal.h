@@ -74,6 +74,16 @@ struct PathPool {
     hipEvent_t ev_poll[2] = {nullptr, nullptr}, ev_done = nullptr;
     uint32_t* h_poll = nullptr;              // two pinned words the host polls for the end of the lane's work
     std::vector<hipEvent_t> kernel_events;   // reused by RTX_FLAG_TIME_KERNELS, 3 per round
+    // Launch records of the single-launch render are uploaded from pinned memory, so that a call may return before its
+    // work has run (RTX_FLAG_NO_WAIT): a small ring of them, each guarded by an event that says its upload has executed.
+    static constexpr uint32_t RING = 8;
+    DRenderCtl* h_ctl_ring = nullptr;
+    DRenderParams* h_params_ring = nullptr;
+    hipEvent_t ring_ev[RING] = {};
+    bool ring_used[RING] = {};
+    uint32_t ring_next = 0;
+    int ensure_ring();
+    int ring_acquire(uint32_t* slot);   // waits until the slot's previous upload has executed
 
     ~PathPool();
     int ensure_host_side();

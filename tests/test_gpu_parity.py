@@ -164,6 +164,30 @@ def test_undecided_boxes_in_loop_and_batched(rt, oracle, name, batch, monkeypatc
         d = rng.normal(size=org.shape)
 
 
+@pytest.mark.parametrize("name", ["cover_spheres", "demo_spheres", "simple_scene", "soup_spheres"])
+def test_trace_closest_equals_the_brute_force_list(rt, oracle, name):
+    """`impl Hittable for &[Surface]` (src/surface.rs:40-59: every surface tested, strict `<`, first wins ties) needs no tree at
+    all.  For spheres the tree's boxes enclose their surfaces, so the tree can only skip surfaces that the list would reject
+    as well: same hit and same distance wherever no two surfaces tie."""
+    if name == "soup_spheres":
+        surfaces, cam = S.synthetic_soup(n=3000, kind="spheres", seed=21, image_width=320)
+    else:
+        surfaces, cam = S.EXAMPLES[name]()
+        cam = dict(cam, image_width=min(cam["image_width"], 320))
+    dev, orc = rt.Scene(rt.HostBVH(surfaces)), oracle.Scene(surfaces)
+    org, d = rt.primary_rays(rt.camera_initialize(cam), 31, 0)
+    rng = np.random.default_rng(17)
+    for bounce in range(2):
+        ids, t, _ = dev.trace_closest(org, d)
+        lid, lt = orc.trace_bruteforce(org, d)
+        same_t = bits(t) == bits(np.where(lid == NONE, np.inf, lt))
+        assert same_t.all()
+        assert (ids == lid)[same_t].mean() > 0.9999      # equal distances to two different spheres: the two orders may differ
+        hit = ids != NONE
+        org = org[hit] + d[hit] * t[hit, None]
+        d = rng.normal(size=org.shape)
+
+
 def test_trace_closest_interval_and_ties(rt, oracle):
     lam = S.lambertian((1, 1, 1))
     surf = S.pack([S.quad((0, 0, 0), (1, 0, 0), (0, 1, 0), lam), S.quad((0, 0, 0), (1, 0, 0), (0, 1, 0), lam),
@@ -337,6 +361,33 @@ def test_sample_ranges_add_up(rt):
     other_seed = torch.zeros_like(whole)
     dev.render_accumulate(icam, 5, 0, 8, other_seed.data_ptr(), stream)
     assert not torch.allclose(whole, other_seed, rtol=1e-3)
+
+
+def test_render_accumulate_without_waiting(rt):
+    """RTX_FLAG_NO_WAIT: the call returns once its launch is enqueued; ten calls in a row on one stream (more than the
+    ring of upload records holds) add up to the image of the waiting calls."""
+    import torch
+
+    surfaces, cam = S.cover_spheres()
+    icam = rt.camera_initialize(dict(cam, image_width=256))
+    dev = rt.Scene(rt.HostBVH(surfaces))
+    side = torch.cuda.Stream()
+    want = torch.zeros(icam.image_height, icam.image_width, 3, dtype=torch.float64, device="cuda")
+    got = torch.zeros_like(want)
+    torch.cuda.synchronize()
+    rays = 0
+    for k in range(10):
+        rays += dev.render_accumulate(icam, 9, 2 * k, 2, want.data_ptr(), torch.cuda.current_stream().cuda_stream).rays
+    with torch.cuda.stream(side):
+        for k in range(10):
+            st = dev.render_accumulate(icam, 9, 2 * k, 2, got.data_ptr(), side.cuda_stream, rt.FLAG_NO_WAIT)
+            assert st.rays == 0 and st.ms_total == 0.0      # nothing is known yet when the call returns
+        side.synchronize()
+    assert rays > 0 and torch.allclose(got, want, rtol=1e-13, atol=0)
+    for bad in (rt.FLAG_COUNT_WORK, rt.FLAG_EXACT_DIVIDE, rt.FLAG_F64_FILTER, rt.FLAG_TIME_KERNELS):
+        with pytest.raises(rt.RtxError) as e:
+            dev.render_accumulate(icam, 9, 0, 1, got.data_ptr(), side.cuda_stream, rt.FLAG_NO_WAIT | bad)
+        assert e.value.code == -1
 
 
 def test_headline_size_properties(rt, oracle):
