@@ -26,6 +26,7 @@
 
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -39,12 +40,20 @@ namespace build {
 using scan::BLOCK;
 using scan::TILE;
 using scan::run_scan;
+using scan::block_scan_dir;
 constexpr unsigned long long NO_COST = ~0ull;
 
 enum : uint32_t { ERR_NO_PLANE = 1, ERR_EMPTY_SIDE = 2, ERR_INTERNAL = 3 };
+// Control words, 256 bytes apart: the count a level adds to with atomics must not share a line with words its threads read.
+// ctl[ctl_count(level)] = segments of a level.
+constexpr uint32_t CTL_STRIDE = 64, CTL_ERR = 4 * CTL_STRIDE, CTL_WORDS = 5 * CTL_STRIDE, REPORT_WORDS = 4;
+__host__ __device__ constexpr uint32_t ctl_count(uint32_t level) { return (level & 3u) * CTL_STRIDE; }
+// cost of a position whose key equals the next position's: the cost at the end of that run of equal keys
+constexpr unsigned long long TIED = ~0ull - 1ull;
 
 struct DBuild {
     uint32_t n, strategy, buckets, n_nodes;
+    uint32_t n_pad;          // n rounded up to a multiple of four: row stride of cand_cost
     const double* box;       // [n][6] leaf boxes by surface: min xyz, max xyz
     double* cen;             // [3][n] centroid coordinate by surface
     uint32_t* order[2];      // surface at each position of the current order (this level / next level)
@@ -55,20 +64,24 @@ struct DBuild {
     uint32_t* seg_a[2];      // segments (nodes still to split) of this level / the next: first position,
     uint32_t* seg_b[2];      //   one past the last,
     uint32_t* seg_node[2];   //   pre-order node index
-    uint32_t* seg_axis;      // decision per segment of this level
+    uint4* seg_rec[2];       // per segment of this level / the next: {first position, size, area factor of its box (a double)}
+    uint4* seg_cut;          // decision per segment of this level: {n_left | strict << 31, axis, plane (a double)}
+    uint32_t* seg_axis;      // the same, field by field
     double* seg_plane;
     uint32_t* seg_nleft;     // bit 31: predicate is `<` (midpoint) instead of `<=`
     uint32_t* seg_child[2];  // segment index of the left / right child at the next level, NONE for a leaf
-    unsigned long long* best_cost;
-    uint32_t* best_idx;
+    unsigned long long* best_cost[2];   // by segment of this level / the next
+    uint32_t* best_idx[2];
     unsigned long long* cand_cost;   // [3][n]
-    double* L;               // [3][n][6] box of the segment's sorted surfaces up to and including a position
-    double* R;               // [3][n][6] ... from a position to the segment's end
-    uint4* flags;            // predicate of the element at a position of {order, sid[0], sid[1], sid[2]}
-    uint4* P;                // [n+1] exclusive prefix sums of flags
+    double* L;               // [3][n][6] box of the segment's sorted surfaces up to and including a position (not PerSurface)
+    double* R;               // [3][n][6] ... from a position to the segment's end (EqualSize only)
+    uint8_t* flags;          // bit k: predicate of the element at a position of {order, sid[0], sid[1], sid[2]}[k]
+    uint32_t* before;        // [n] passing elements of the position's segment before it in the surface order
     uint32_t* F;             // positions of the failing elements of a segment's left part, in order
     uint32_t* G;             // positions of the passing elements of its right part, from the end
-    uint32_t* ctl;           // [0] segments of the next level, [1] error
+    uint32_t* ctl;           // control words, see ctl_count / CTL_ERR
+    uint32_t* report;        // [REPORT_WORDS] what the host reads after a level: its segments, the next level's, error
+    double* seg_box;         // [n][6] box of every segment of this level (PerSurface; the SAH passes fold it)
     uint32_t* leaf_node;     // [n] node index of the leaf at a position
     uint32_t* node_right;    // outputs, [n_nodes]
     uint32_t* node_prim;
@@ -98,6 +111,171 @@ __device__ __forceinline__ SBox shfl_up_t(const SBox& x, uint32_t d) {
     return r;
 }
 
+__device__ __forceinline__ SBox shfl_down_t(const SBox& x, uint32_t d) {
+    SBox r;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r.v[k] = __shfl_down(x.v[k], d);
+    r.f = __shfl_down(x.f, d);
+    return r;
+}
+
+// AABB::merge (src/aabb.rs:40-53) folded along a list, starting again wherever a segment starts
+struct BoxOp {
+    using T = SBox;
+    __device__ SBox identity() const {
+        SBox r;
+        r.v[0] = r.v[1] = r.v[2] = __longlong_as_double(0x7FF0000000000000ll);
+        r.v[3] = r.v[4] = r.v[5] = __longlong_as_double((long long)0xFFF0000000000000ull);
+        r.f = 0;
+        return r;
+    }
+    __device__ SBox combine(const SBox& a, const SBox& b) const {
+        SBox r;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            r.v[k] = b.f ? b.v[k] : fmin(a.v[k], b.v[k]);
+            r.v[3 + k] = b.f ? b.v[3 + k] : fmax(a.v[3 + k], b.v[3 + k]);
+        }
+        r.f = a.f | b.f;
+        return r;
+    }
+};
+
+// The segmented scan of boxes over a block, built to need few registers and no trip through LDS per step.
+//  * Over a wave: shifts within rows of 16 lanes (DPP row_shr / row_shl), then the row totals handed on by readlane.
+//    The shuffle scan of rtx_scan.h gives the same result (the fold is associative) but waits for an LDS permute of
+//    thirteen registers at each of its steps.
+//  * Where a lane takes in its neighbour's value depends on the segment starts only, not on the values: those decisions
+//    are made once (SegPlan) and the six coordinates are then scanned one after the other, a pair of registers at a time.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    return __hiloint2double((int)dpp_u32<CTRL>((uint32_t)__double2hiint(v)), (int)dpp_u32<CTRL>((uint32_t)__double2loint(v)));
+}
+__device__ __forceinline__ double lane_f64(double v, int from) {   // the value of one lane, to all
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), from), __builtin_amdgcn_readlane(__double2loint(v), from));
+}
+// AABB::merge of one coordinate (src/aabb.rs:40-53): minima for the lower corner (c < 3), maxima for the upper
+__device__ __forceinline__ double merge_coordinate(int c, double a, double b) { return c < 3 ? fmin(a, b) : fmax(a, b); }
+
+template <bool REV>
+struct SegPlan {
+    uint32_t rank, wrank;   // place of the lane in its wave and of the wave in the block, in scan order
+    bool take1, take2, take4, take8, take_a, take_b;   // the lane takes in: the lane 1, 2, 4, 8 before it in its row; the rows before
+    bool closed;            // a segment starts in this wave at or before this lane
+    bool before_closed;     // ... at or before the lane before this one
+    bool wave_closed[scan::WAVES];   // ... anywhere in wave w (scan order)
+    // flags: whether a segment starts at this thread's items (any of them)
+    __device__ __forceinline__ void make(bool starts, uint32_t* lds_f) {
+        const uint32_t l = lane();
+        rank = REV ? 63u - l : l;
+        wrank = REV ? scan::WAVES - 1u - (threadIdx.x >> 6) : (threadIdx.x >> 6);
+        const uint32_t in_row = rank & 15u, row = rank >> 4;
+        uint32_t f = starts ? 1u : 0u, p;
+        p = REV ? dpp_u32<0x101>(f) : dpp_u32<0x111>(f);
+        take1 = in_row >= 1u && !f;
+        if (in_row >= 1u) f |= p;
+        p = REV ? dpp_u32<0x102>(f) : dpp_u32<0x112>(f);
+        take2 = in_row >= 2u && !f;
+        if (in_row >= 2u) f |= p;
+        p = REV ? dpp_u32<0x104>(f) : dpp_u32<0x114>(f);
+        take4 = in_row >= 4u && !f;
+        if (in_row >= 4u) f |= p;
+        p = REV ? dpp_u32<0x108>(f) : dpp_u32<0x118>(f);
+        take8 = in_row >= 8u && !f;
+        if (in_row >= 8u) f |= p;
+        // the last lane of a row in scan order holds the row's flag
+        const uint32_t f15 = (uint32_t)__builtin_amdgcn_readlane((int)f, REV ? 48 : 15), f47 = (uint32_t)__builtin_amdgcn_readlane((int)f, REV ? 16 : 47);
+        take_a = (row == 1u || row == 3u) && !f;
+        if (row == 1u) f |= f15;
+        if (row == 3u) f |= f47;
+        const uint32_t f31 = (uint32_t)__builtin_amdgcn_readlane((int)f, 32 - (REV ? 0 : 1));   // rank 31: lane 31, REV lane 32
+        take_b = row >= 2u && !f;
+        if (row >= 2u) f |= f31;
+        closed = f != 0u;
+        before_closed = (REV ? __shfl_down(f, 1) : __shfl_up(f, 1)) != 0u;
+        if (rank == 63u) lds_f[wrank] = f;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t w = 0; w < scan::WAVES; ++w) wave_closed[w] = lds_f[w] != 0u;
+    }
+    // inclusive scan of one coordinate of the threads' folds over the wave
+    __device__ __forceinline__ double wave(int c, double v) const {
+        double p;
+        p = REV ? dpp_f64<0x101>(v) : dpp_f64<0x111>(v);
+        if (take1) v = merge_coordinate(c, p, v);
+        p = REV ? dpp_f64<0x102>(v) : dpp_f64<0x112>(v);
+        if (take2) v = merge_coordinate(c, p, v);
+        p = REV ? dpp_f64<0x104>(v) : dpp_f64<0x114>(v);
+        if (take4) v = merge_coordinate(c, p, v);
+        p = REV ? dpp_f64<0x108>(v) : dpp_f64<0x118>(v);
+        if (take8) v = merge_coordinate(c, p, v);
+        const double r15 = lane_f64(v, REV ? 48 : 15), r47 = lane_f64(v, REV ? 16 : 47);
+        if (take_a) v = merge_coordinate(c, (rank >> 4) == 1u ? r15 : r47, v);
+        const double r31 = lane_f64(v, REV ? 32 : 31);
+        if (take_b) v = merge_coordinate(c, r31, v);
+        return v;
+    }
+};
+
+// Inclusive segmented scan of BLOCK*N boxes held N per thread as coordinates x[i][0..5]; REV: from the block's last box to its
+// first.  starts: bit i = a segment starts at item i (REV: ends there).  carry (may be null: nothing) = what lies before
+// the block, carry_closed = it holds a segment start.  On return x holds the scan; if total is given, thread 0 stores the
+// fold of carry and block there.  lds_v / lds_f: scan::WAVES entries each.  Two barriers.
+template <bool REV, uint32_t N>
+__device__ __forceinline__ void block_scan_boxes(double (&x)[N][6], uint32_t starts, const double* carry, SBox* total, double (*lds_v)[6], uint32_t* lds_f) {
+    // what of the thread's own items lies before item i in scan order, and whether item i is open to what comes before the thread
+    bool open[N];
+    {
+        bool any = false;
+#pragma unroll
+        for (uint32_t k = 0; k < N; ++k) {
+            const uint32_t i = REV ? N - 1u - k : k;
+            any = any || ((starts >> i) & 1u);
+            open[i] = !any;
+        }
+    }
+    SegPlan<REV> plan;
+    plan.make(starts != 0u, lds_f);
+    double inc[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (uint32_t k = 1; k < N; ++k) {
+            const uint32_t i = REV ? N - 1u - k : k, prev = REV ? i + 1u : i - 1u;
+            if (!((starts >> i) & 1u)) x[i][c] = merge_coordinate(c, x[prev][c], x[i][c]);
+        }
+        inc[c] = plan.wave(c, x[REV ? 0 : N - 1u][c]);
+        if (plan.rank == 63u) lds_v[plan.wrank][c] = inc[c];
+    }
+    __syncthreads();
+    bool total_closed = false;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const double identity = __longlong_as_double(c < 3 ? 0x7FF0000000000000ll : (long long)0xFFF0000000000000ull);
+        double prefix = carry ? carry[c] : identity, all = prefix;
+#pragma unroll
+        for (uint32_t w = 0; w < scan::WAVES; ++w) {
+            const double t = lds_v[w][c];
+            if (w < plan.wrank) prefix = plan.wave_closed[w] ? t : merge_coordinate(c, prefix, t);
+            all = plan.wave_closed[w] ? t : merge_coordinate(c, all, t);
+        }
+        const double before = REV ? __shfl_down(inc[c], 1) : __shfl_up(inc[c], 1);
+        if (plan.rank > 0u) prefix = plan.before_closed ? before : merge_coordinate(c, prefix, before);
+#pragma unroll
+        for (uint32_t i = 0; i < N; ++i)
+            if (open[i]) x[i][c] = merge_coordinate(c, prefix, x[i][c]);
+        if (total && threadIdx.x == 0) total->v[c] = all;
+    }
+#pragma unroll
+    for (uint32_t w = 0; w < scan::WAVES; ++w) total_closed = total_closed || plan.wave_closed[w];
+    if (total && threadIdx.x == 0) total->f = total_closed ? 1u : 0u;   // (the carry's own flag plays no part in a tile total)
+    __syncthreads();
+}
+
 // Row y = axis + 3*direction.  Direction 0 folds the boxes of a segment's
 // sorted surfaces from its first position on (left_of, partition.rs:136-150),
 // direction 1 from its last position back (right_of, partition.rs:152-166).
@@ -105,20 +283,16 @@ struct BoxScan {
     using T = SBox;
     DBuild B;
     uint32_t cur;
-    __device__ T identity() const {
-        T r;
-        r.v[0] = r.v[1] = r.v[2] = __longlong_as_double(0x7FF0000000000000ll);
-        r.v[3] = r.v[4] = r.v[5] = __longlong_as_double((long long)0xFFF0000000000000ull);
-        r.f = 0;
-        return r;
-    }
+    __device__ T identity() const { return BoxOp{}.identity(); }
     __device__ T load(uint32_t i, uint32_t y) const {
         const uint32_t axis = y % 3u, back = y / 3u;
         const uint32_t pos = back ? B.n - 1u - i : i;
         const uint32_t s = B.seg_at[pos];
         T r = identity();
         r.f = 1;
-        if (s == NONE) return r;   // a finished leaf: a segment of its own, value never read
+        // a finished leaf: a segment of its own, value never read.  After a failed level the lists of this one were never
+        // written: nothing is read through them (the host stops two levels late).
+        if (s == NONE || B.ctl[CTL_ERR] != 0u) return r;
         const bool edge = back ? pos == B.n - 1u : pos == 0u;
         r.f = (edge || B.seg_at[back ? pos + 1u : pos - 1u] != s) ? 1u : 0u;
         // bisection keeps no sorted lists: the fold over the surface order gives the same box
@@ -128,37 +302,44 @@ struct BoxScan {
         for (int k = 0; k < 6; ++k) r.v[k] = b[k];
         return r;
     }
-    // AABB::merge, src/aabb.rs:40-53
-    __device__ T combine(const T& a, const T& b) const {
-        T r;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            r.v[k] = b.f ? b.v[k] : fmin(a.v[k], b.v[k]);
-            r.v[3 + k] = b.f ? b.v[3 + k] : fmax(a.v[3 + k], b.v[3 + k]);
-        }
-        r.f = a.f | b.f;
-        return r;
-    }
+    __device__ T combine(const T& a, const T& b) const { return BoxOp{}.combine(a, b); }
     __device__ void store(uint32_t i, uint32_t y, const T& inc) const {
         const uint32_t axis = y % 3u, back = y / 3u;
         const uint32_t pos = back ? B.n - 1u - i : i;
-        if (B.seg_at[pos] == NONE) return;
+        if (B.seg_at[pos] == NONE || B.ctl[CTL_ERR] != 0u) return;
         double* out = (back ? B.R : B.L) + ((size_t)axis * B.n + pos) * 6u;
 #pragma unroll
         for (int k = 0; k < 6; ++k) out[k] = inc.v[k];
     }
 };
 
-struct FlagScan {
-    using T = uint4;
-    DBuild B;
-    __device__ T identity() const { return make_uint4(0, 0, 0, 0); }
-    __device__ T load(uint32_t i, uint32_t) const { return B.flags[i]; }
-    __device__ T combine(const T& a, const T& b) const { return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-    __device__ void store(uint32_t i, uint32_t, const T& inc) const {
-        const uint4 f = B.flags[i];
-        B.P[i] = make_uint4(inc.x - f.x, inc.y - f.y, inc.z - f.z, inc.w - f.w);
-        if (i == B.n - 1u) B.P[B.n] = inc;
+// Passing elements of a segment up to a position, for the four lists at once.
+struct SCount {
+    uint32_t c[4];
+    uint32_t f;   // a segment starts at this element
+};
+__device__ __forceinline__ SCount shfl_up_t(const SCount& x, uint32_t d) {
+    SCount r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.c[k] = __shfl_up(x.c[k], d);
+    r.f = __shfl_up(x.f, d);
+    return r;
+}
+__device__ __forceinline__ SCount shfl_down_t(const SCount& x, uint32_t d) {
+    SCount r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.c[k] = __shfl_down(x.c[k], d);
+    r.f = __shfl_down(x.f, d);
+    return r;
+}
+struct CountOp {
+    __device__ SCount identity() const { return SCount{{0, 0, 0, 0}, 0}; }
+    __device__ SCount combine(const SCount& a, const SCount& b) const {
+        SCount r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.c[k] = b.f ? b.c[k] : a.c[k] + b.c[k];
+        r.f = a.f | b.f;
+        return r;
     }
 };
 
@@ -191,16 +372,18 @@ __device__ __forceinline__ double area_factor(const double* b) {
     return dx * dy + dx * dz + dy * dz;
 }
 // surface_area_heuristic, partition.rs:92-106, in the reference's order of operations
-__device__ __forceinline__ double split_cost(const double* left, uint32_t n_left, const double* right, uint32_t n_right, const double* bb) {
-    const double parent = area_factor(bb);
-    const double p_left = area_factor(left) / parent;
-    const double p_right = area_factor(right) / parent;
+__device__ __forceinline__ double split_cost_areas(double area_left, uint32_t n_left, double area_right, uint32_t n_right, double parent) {
+    const double p_left = area_left / parent;
+    const double p_right = area_right / parent;
     const double cost = 1.0 + p_left * (double)n_left + p_right * (double)n_right;
     // A parent box without area (zero-radius spheres on a line) makes the cost 0/0.  total_cmp orders NaNs by their sign,
     // and the default NaN of the hosts the reference and the host builder run on (x86-64) is the negative one, which
     // min_by ranks lowest; this device's default NaN is the positive one.  Every NaN cost takes the host's form, so
     // that both builders pick the same plane for such a segment.
     return cost != cost ? __longlong_as_double((long long)0xFFF8000000000000ull) : cost;
+}
+__device__ __forceinline__ double split_cost(const double* left, uint32_t n_left, const double* right, uint32_t n_right, const double* bb) {
+    return split_cost_areas(area_factor(left), n_left, area_factor(right), n_right, area_factor(bb));
 }
 
 __device__ __forceinline__ double cost_of_split(const DBuild& B, uint32_t axis, uint32_t a, uint32_t b, uint32_t k) {
@@ -210,58 +393,389 @@ __device__ __forceinline__ double cost_of_split(const DBuild& B, uint32_t axis, 
     return split_cost(left, k, right, (b - a) - k, bb);
 }
 
-// atomicMin(&table[s], v) for the lanes with s != NONE; one atomic per wave when all of them share s
+// An atomic minimum that first looks whether it would change anything.  Near the root thousands of waves report
+// to the same few words, and atomics on one address are served one after the other: the look (past the compute unit's
+// cache, which may hold the word as it was before the launch) lets all but the first few go without.
+__device__ __forceinline__ void lazy_min(unsigned long long* p, unsigned long long v) {
+    if (v < __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(p, v);
+}
+// Where the cheapest cost of segment s is kept: the first segments of a level, which whole blocks report to, have a
+// 128-byte line each.
+constexpr uint32_t BEST_APART = 4096, BEST_EXTRA = BEST_APART * 16u;
+__host__ __device__ __forceinline__ uint32_t best_slot(uint32_t s) { return s < BEST_APART ? s * 16u : BEST_EXTRA + (s - BEST_APART); }
+// atomicMin(&table[best_slot(s)], v) for the lanes with s != NONE.  Lanes hold consecutive positions, so the lanes of a
+// segment are a run: a segmented scan leaves the minimum of every run in its last lane, which reports for the run.
 __device__ __forceinline__ void segment_min(unsigned long long* table, uint32_t s, unsigned long long v) {
-    const bool live = s != NONE && v != NO_COST;
-    const unsigned long long mask = __ballot(live);
-    if (mask == 0ull) return;
-    const uint32_t first = (uint32_t)__ffsll((long long)mask) - 1u;
-    const uint32_t s0 = __shfl(s, first);
-    if (__ballot(live && s != s0) == 0ull) {
-        unsigned long long m = live ? v : NO_COST;
+    if (__ballot(s != NONE && v != NO_COST) == 0ull) return;
+    const uint32_t l = lane();
+    unsigned long long m = s != NONE ? v : NO_COST;
 #pragma unroll
-        for (uint32_t d = 32; d >= 1; d >>= 1) {
-            const unsigned long long o = __shfl_xor(m, d);
-            m = o < m ? o : m;
-        }
-        if (lane() == first) atomicMin(&table[s0], m);
-    } else if (live) {
-        atomicMin(&table[s], v);
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(m, d);
+        const uint32_t os = __shfl_up(s, d);
+        if (l >= d && os == s) m = o < m ? o : m;   // (a run is contiguous: if the lane d below is of this segment, so are all between)
     }
+    const uint32_t next = __shfl_down(s, 1);
+    if (s != NONE && m != NO_COST && (l == 63u || next != s)) lazy_min(&table[best_slot(s)], m);
 }
 
-// PerSurface (partition.rs:254-266): every surface's centroid coordinate on
-// every axis is a candidate plane.  One thread per (axis, position of the
-// axis' sorted order).
-__global__ void __launch_bounds__(BLOCK) k_candidates_per_surface(DBuild B, uint32_t cur) {
-    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x, axis = blockIdx.y;
-    const uint32_t s = pos < B.n ? B.seg_at[pos] : NONE;
-    unsigned long long ck = NO_COST;
-    if (s != NONE) {
-        const uint32_t a = B.seg_a[cur][s], b = B.seg_b[cur][s];
-        const double* key = B.skey[cur][axis];
-        const double at = key[pos];
-        uint32_t k = 0;
-        if (pos + 1u < b) k = key[pos + 1u] > at ? pos + 1u - a : n_left_for(key + a, b - a, at);
-        if (k) ck = ordered_key(cost_of_split(B, axis, a, b, k));
-        B.cand_cost[(size_t)axis * B.n + pos] = ck;
+// N consecutive 32-bit entries of a table from `base` on, a multiple of N; every table is padded to 256 bytes, so they come
+// in one load even where the table's last entries are not all there (what lies beyond n is not used).
+template <uint32_t N>
+__device__ __forceinline__ void load_run(const uint32_t* table, uint32_t base, uint32_t n, uint32_t (&out)[N]) {
+    static_assert(N == 1 || N == 2 || N == 4, "one load per thread");
+#pragma unroll
+    for (uint32_t i = 0; i < N; ++i) out[i] = NONE;
+    if (base >= n) return;
+    if (N == 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(table + base);
+        out[0] = v.x; out[1 % N] = v.y; out[2 % N] = v.z; out[3 % N] = v.w;
+    } else if (N == 2) {
+        const uint2 v = *reinterpret_cast<const uint2*>(table + base);
+        out[0] = v.x; out[1 % N] = v.y;
+    } else {
+        out[0] = table[base];
     }
-    segment_min(B.best_cost, s, ck);
 }
-__global__ void __launch_bounds__(BLOCK) k_pick_per_surface(DBuild B, uint32_t cur) {
+// Segment of the positions base-1 .. base+N of a thread's items, NONE outside the list.
+template <uint32_t N>
+__device__ __forceinline__ void load_segments(const DBuild& B, uint32_t base, uint32_t (&sg)[N + 2]) {
+    const uint32_t n = B.n;
+    uint32_t own[N];
+    load_run<N>(B.seg_at, base, n, own);
+    sg[0] = base - 1u < n ? B.seg_at[base - 1u] : NONE;
+#pragma unroll
+    for (uint32_t i = 0; i < N; ++i) sg[i + 1u] = base + i < n ? own[i] : NONE;
+    sg[N + 1u] = base + N < n ? B.seg_at[base + N] : NONE;
+}
+
+// PerSurface (partition.rs:254-266): every surface's centroid coordinate on every axis is a candidate plane.  The cost of
+// the plane at a position of an axis' sorted order needs the box of the segment's surfaces up to that position and the box
+// of those behind it (left_of / right_of, partition.rs:136-166): a forward and a backward segmented scan of the boxes.
+// Neither scan is written to memory.  A block scans its tile both ways; a first pass (APPLY = false) leaves every tile's
+// totals and folds the box of every segment (the parent in the cost, partition.rs:93, and the node's box), the second
+// takes what the scans carry into the tile and prices its positions on the spot.  The carry comes from the totals: either
+// they have been scanned in between (SPINED, worth a launch while segments span many tiles) or the block folds the
+// totals next to it back to the nearest segment start.  Positions whose key equals the next one's share the plane, and
+// so the cost, of the last position of that run of equal keys (split_at, partition.rs:182-197): they are marked TIED and
+// looked up when the winner is picked.
+// totals: rows 0-2 forward per axis by tile, rows 3-5 backward per axis by tile counted from the end.
+#ifndef RTX_SAH_WAVES
+#define RTX_SAH_WAVES 4
+#endif
+#ifndef RTX_SAH_ITEMS
+#define RTX_SAH_ITEMS 2
+#endif
+constexpr int SAH_WAVES = RTX_SAH_WAVES;   // waves per SIMD the register budget of the kernels below allows
+constexpr uint32_t SAH_ITEMS = RTX_SAH_ITEMS, SAH_TILE = BLOCK * SAH_ITEMS;   // positions per thread and per block
+
+// exclusive scan of every row of tile totals (one block per row); only the boxes of the result are used
+__global__ void __launch_bounds__(BLOCK) k_box_spine(uint32_t n_tiles, SBox* totals) {
+    __shared__ double lds_v[scan::WAVES][6];
+    __shared__ uint32_t lds_f[scan::WAVES];
+    __shared__ double edge[scan::WAVES][6];
+    __shared__ SBox running[2];   // what precedes the chunk / the chunk after this one
+    SBox* row = totals + (size_t)blockIdx.x * n_tiles;
+    const uint32_t wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) running[0] = BoxOp{}.identity();
+    __syncthreads();
+    uint32_t which = 0;
+    for (uint32_t first = 0; first < n_tiles; first += BLOCK, which ^= 1u) {
+        const uint32_t i = first + threadIdx.x;
+        double x[1][6];
+        uint32_t starts = 0;
+        {
+            const SBox t = i < n_tiles ? row[i] : BoxOp{}.identity();
+#pragma unroll
+            for (int c = 0; c < 6; ++c) x[0][c] = t.v[c];
+            starts = t.f ? 1u : 0u;
+        }
+        block_scan_boxes<false, 1>(x, starts, running[which].v, &running[which ^ 1u], lds_v, lds_f);
+        // exclusive: the scan of the thread before
+        if (lane() == 63)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) edge[wave][c] = x[0][c];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double before = __shfl_up(x[0][c], 1);
+            const double excl = lane() > 0 ? before : (wave > 0 ? edge[wave - 1u][c] : running[which].v[c]);
+            if (i < n_tiles) row[i].v[c] = excl;
+        }
+        __syncthreads();
+    }
+}
+// What a scan carries into tile `tile` of a row of tile totals: the fold of the totals before it, from the nearest total
+// that holds a segment start on.  Returns where the box lies (null: nothing precedes); whole block, uniform.
+__device__ __forceinline__ const double* look_back_boxes(const SBox* row, uint32_t tile, SBox* acc, SBox* chunk, double (*lds_v)[6], uint32_t* lds_f) {
+    if (tile == 0u) return nullptr;
+    if (row[tile - 1u].f) return row[tile - 1u].v;   // deep in the tree every tile holds a segment start: the neighbour is all there is
+    if (threadIdx.x == 0) *acc = BoxOp{}.identity();
+    for (uint32_t done = 0; done < tile; done += BLOCK) {
+        const uint32_t j = done + threadIdx.x;   // distance from the tile, less one
+        double x[1][6];
+        uint32_t starts = 0;
+        {
+            const SBox t = j < tile ? row[tile - 1u - j] : BoxOp{}.identity();
+#pragma unroll
+            for (int c = 0; c < 6; ++c) x[0][c] = t.v[c];
+            starts = t.f ? 1u : 0u;
+        }
+        block_scan_boxes<true, 1>(x, starts, nullptr, chunk, lds_v, lds_f);   // the farthest first
+        if (threadIdx.x == 0) *acc = BoxOp{}.combine(*chunk, *acc);
+        __syncthreads();
+        if (acc->f) break;
+    }
+    return acc->v;
+}
+
+// PerSurface (partition.rs:254-266): every surface's centroid coordinate on every axis is a candidate plane.  The cost of
+// the plane at a position of an axis' sorted order needs the box of the segment's surfaces up to that position and the box
+// of those behind it (left_of / right_of, partition.rs:136-166): a forward and a backward segmented scan of the boxes.
+// Neither scan is written to memory.  A block scans its tile both ways; a first pass (APPLY = false) leaves every tile's
+// totals and folds the box of every segment (the parent in the cost, partition.rs:93, and the node's box), the second
+// takes what the scans carry into the tile and prices its positions on the spot.  The carry comes from the totals: either
+// they have been scanned in between (SPINED, worth a launch while segments span many tiles) or the block folds the
+// totals next to it back to the nearest segment start.  Positions whose key equals the next one's share the plane, and
+// so the cost, of the last position of that run of equal keys (split_at, partition.rs:182-197): they are marked TIED and
+// looked up when the winner is picked.
+// totals: rows 0-2 forward per axis by tile, rows 3-5 backward per axis by tile counted from the end.
+template <bool APPLY, bool SPINED>
+__global__ void __launch_bounds__(BLOCK, SAH_WAVES) k_sah_per_surface(DBuild B, uint32_t cur, uint32_t level, SBox* totals) {
+    __shared__ double lds_v[scan::WAVES][6];
+    __shared__ uint32_t lds_f[scan::WAVES];
+    __shared__ double edge[scan::WAVES];
+    __shared__ SBox look[2];
+    if (B.ctl[ctl_count(level)] == 0u || B.ctl[CTL_ERR] != 0u) return;
+    constexpr uint32_t ITEMS = SAH_ITEMS;
+    const uint32_t n = B.n, tile = blockIdx.x, axis = blockIdx.y, n_tiles = gridDim.x, tile_b = n_tiles - 1u - tile;
+    const uint32_t base = tile * SAH_TILE + threadIdx.x * ITEMS;
+    uint32_t sg[ITEMS + 2];
+    load_segments<ITEMS>(B, base, sg);
+    uint32_t list[ITEMS];
+    load_run<ITEMS>(B.sid[cur][axis], base, n, list);
+    double raw[ITEMS][6], x[ITEMS][6];
+    uint32_t starts = 0, ends = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < ITEMS; ++i) {
+        const uint32_t pos = base + i, s = sg[i + 1u];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) raw[i][c] = __longlong_as_double(c < 3 ? 0x7FF0000000000000ll : (long long)0xFFF0000000000000ull);
+        if (pos < n) {
+            if (s == NONE) {   // a finished leaf: a segment of its own
+                starts |= 1u << i;
+                ends |= 1u << i;
+            } else {
+                starts |= (uint32_t)(sg[i] != s) << i;
+                ends |= (uint32_t)(sg[i + 2u] != s) << i;
+                const double2* b = reinterpret_cast<const double2*>(B.box + 6ull * list[i]);   // 48 bytes apart: 16-byte aligned
+                const double2 b0 = b[0], b1 = b[1], b2 = b[2];
+                raw[i][0] = b0.x; raw[i][1] = b0.y; raw[i][2] = b1.x; raw[i][3] = b1.y; raw[i][4] = b2.x; raw[i][5] = b2.y;
+            }
+        }
+    }
+    SBox* const row_f = totals + (size_t)axis * n_tiles;
+    SBox* const row_b = totals + (size_t)(3u + axis) * n_tiles;
+    if (!APPLY) {
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; ++i)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) x[i][c] = raw[i][c];
+        block_scan_boxes<true, ITEMS>(x, ends, nullptr, &row_b[tile_b], lds_v, lds_f);
+        block_scan_boxes<false, ITEMS>(raw, starts, nullptr, &row_f[tile], lds_v, lds_f);
+        if (axis != 0u) return;
+        // The segment's box: at a segment's last position the scan holds the fold since the segment's start, or since the
+        // tile's if the segment started before it; the rest follows from the tile totals (k_segment_areas).
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; ++i) {
+            const uint32_t pos = base + i, s = sg[i + 1u];
+            if (pos >= n || s == NONE || !((ends >> i) & 1u)) continue;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) B.seg_box[6ull * s + k] = raw[i][k];
+        }
+        return;
+    }
+    double area_behind[ITEMS];   // area factor of the surfaces behind a position: the backward scan one position on
+    {
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; ++i)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) x[i][c] = raw[i][c];
+        const double* carry = SPINED ? row_b[tile_b].v : look_back_boxes(row_b, tile_b, &look[0], &look[1], lds_v, lds_f);
+        block_scan_boxes<true, ITEMS>(x, ends, carry, nullptr, lds_v, lds_f);
+        // ... the next item, the next thread's first, the carry
+        const double own = area_factor(x[0]);
+#pragma unroll
+        for (uint32_t i = 0; i + 1u < ITEMS; ++i) area_behind[i] = area_factor(x[i + 1u]);
+        const uint32_t wave = threadIdx.x >> 6;
+        if (lane() == 0) edge[wave] = own;
+        __syncthreads();
+        double nx = __shfl_down(own, 1);
+        if (lane() == 63) {
+            if (wave + 1u < scan::WAVES) {
+                nx = edge[wave + 1u];
+            } else {
+                double beyond[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) beyond[c] = carry ? carry[c] : 0.0;
+                nx = area_factor(beyond);
+            }
+        }
+        area_behind[ITEMS - 1u] = nx;
+        __syncthreads();   // (the carry may lie in `look`, which the next look-back overwrites)
+    }
+    {
+        const double* carry = SPINED ? row_f[tile].v : look_back_boxes(row_f, tile, &look[0], &look[1], lds_v, lds_f);
+        block_scan_boxes<false, ITEMS>(raw, starts, carry, nullptr, lds_v, lds_f);
+    }
+
+    const double* key = B.skey[cur][axis];
+    double keys[ITEMS + 1];
+    if (ITEMS > 1 && base + ITEMS < n) {
+#pragma unroll
+        for (uint32_t i = 0; i + 1u < ITEMS; i += 2) {
+            const double2 kk = *reinterpret_cast<const double2*>(key + base + i);
+            keys[i] = kk.x;
+            keys[i + 1u] = kk.y;
+        }
+        keys[ITEMS] = key[base + ITEMS];
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i <= ITEMS; ++i) keys[i] = base + i < n ? key[base + i] : 0.0;
+    }
+    uint4 rec[ITEMS];   // first position, size and area factor of the position's segment
+#pragma unroll
+    for (uint32_t i = 0; i < ITEMS; ++i) rec[i] = base + i < n && sg[i + 1u] != NONE ? B.seg_rec[cur][sg[i + 1u]] : make_uint4(0, 0, 0, 0);
+    unsigned long long ck[ITEMS], out[ITEMS];
+    uint32_t ss[ITEMS];
+#pragma unroll
+    for (uint32_t i = 0; i < ITEMS; ++i) {
+        const uint32_t pos = base + i, s = sg[i + 1u];
+        ck[i] = out[i] = NO_COST;   // a segment's last position separates nothing
+        ss[i] = NONE;
+        if (pos < n && s != NONE) {
+            ss[i] = s;
+            if (sg[i + 2u] == s) {
+                if (keys[i + 1u] > keys[i]) {
+                    const uint32_t k = pos + 1u - rec[i].x;
+                    const double parent = __hiloint2double((int)rec[i].w, (int)rec[i].z);
+                    out[i] = ck[i] = ordered_key(split_cost_areas(area_factor(raw[i]), k, area_behind[i], rec[i].y - k, parent));
+                } else {
+                    out[i] = TIED;
+                }
+            }
+        }
+    }
+    unsigned long long* const cand = B.cand_cost + (size_t)axis * B.n_pad + base;   // rows start at multiples of four
+    if (ITEMS > 1 && base + ITEMS <= n) {
+#pragma unroll
+        for (uint32_t i = 0; i + 1u < ITEMS; i += 2) reinterpret_cast<ulonglong2*>(cand)[i / 2u] = make_ulonglong2(out[i], out[i + 1u]);
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; ++i)
+            if (base + i < n) cand[i] = out[i];
+    }
+    // The cheapest per segment.  Near the root a whole block prices positions of one segment: then the block reports once.
+    // Otherwise one call for the threads whose positions share a segment, and the other threads position by position.
+    bool same = true;
+    unsigned long long m = ck[0];
+#pragma unroll
+    for (uint32_t i = 1; i < ITEMS; ++i) {
+        same = same && ss[i] == ss[0];
+        m = ck[i] < m ? ck[i] : m;
+    }
+    __shared__ unsigned long long wave_best[scan::WAVES];
+    __shared__ uint32_t wave_segment[scan::WAVES];
+    constexpr uint32_t MIXED = NONE - 1u;
+    {
+        const unsigned long long with = __ballot(same && ss[0] != NONE);
+        uint32_t s0 = NONE;
+        if (with) s0 = __shfl(ss[0], (int)__ffsll((long long)with) - 1);
+        const bool one = __ballot(!same || (ss[0] != NONE && ss[0] != s0)) == 0ull;
+        unsigned long long w = same && ss[0] != NONE ? m : NO_COST;
+#pragma unroll
+        for (uint32_t d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(w, d);
+            w = o < w ? o : w;
+        }
+        if (lane() == 0) {
+            wave_segment[threadIdx.x >> 6] = one ? s0 : MIXED;
+            wave_best[threadIdx.x >> 6] = w;
+        }
+    }
+    __syncthreads();
+    uint32_t block_segment = NONE;
+    bool block_one = true;
+    unsigned long long block_best = NO_COST;
+#pragma unroll
+    for (uint32_t w = 0; w < scan::WAVES; ++w) {
+        const uint32_t sw = wave_segment[w];
+        if (sw == MIXED || (sw != NONE && block_segment != NONE && sw != block_segment)) block_one = false;
+        if (sw != NONE && sw != MIXED) block_segment = sw;
+        block_best = wave_best[w] < block_best ? wave_best[w] : block_best;
+    }
+    if (block_one) {
+        if (threadIdx.x == 0 && block_segment != NONE && block_best != NO_COST) lazy_min(&B.best_cost[cur][best_slot(block_segment)], block_best);
+        return;
+    }
+    segment_min(B.best_cost[cur], same ? ss[0] : NONE, same ? m : NO_COST);
+    if (__ballot(!same) != 0ull) {
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; ++i) segment_min(B.best_cost[cur], same ? NONE : ss[i], same ? NO_COST : ck[i]);
+    }
+}
+// Completes the box of every segment and notes its area factor (the parent in surface_area_heuristic, partition.rs:93)
+// next to the segment's first position and size: one 16-byte record for the pricing pass.  The first SAH pass left the
+// fold over the segment's positions in its last tile; the tiles before that one are in the totals of the x order
+// (totals scanned already if `spined`: then the entry of the last tile is all that precedes it in the segment).
+__global__ void __launch_bounds__(BLOCK) k_segment_areas(DBuild B, uint32_t cur, uint32_t level, const SBox* row_f, uint32_t spined) {
+    const uint32_t s = blockIdx.x * BLOCK + threadIdx.x;
+    if (s >= B.ctl[ctl_count(level)] || B.ctl[CTL_ERR] != 0u) return;
+    const uint32_t a = B.seg_a[cur][s], b = B.seg_b[cur][s], tile_a = a / SAH_TILE, tile_e = (b - 1u) / SAH_TILE;
+    double bb[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bb[k] = B.seg_box[6ull * s + k];
+    if (tile_a < tile_e) {
+        for (uint32_t t = tile_e; t-- > (spined ? tile_e - 1u : tile_a);) {
+            const SBox& before = row_f[spined ? tile_e : t];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                bb[k] = fmin(before.v[k], bb[k]);
+                bb[3 + k] = fmax(before.v[3 + k], bb[3 + k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) B.seg_box[6ull * s + k] = bb[k];
+    }
+    const double area = area_factor(bb);
+    B.seg_rec[cur][s].z = (uint32_t)__double2loint(area);
+    B.seg_rec[cur][s].w = (uint32_t)__double2hiint(area);
+}
+// min_by keeps the first of equal minima in surface-major, axis-minor order (partition.rs:218,254-266)
+__global__ void __launch_bounds__(BLOCK) k_pick_per_surface(DBuild B, uint32_t cur, uint32_t level) {
+    if (B.ctl[ctl_count(level)] == 0u || B.ctl[CTL_ERR] != 0u) return;
     const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x, axis = blockIdx.y;
     if (pos >= B.n) return;
     const uint32_t s = B.seg_at[pos];
     if (s == NONE) return;
-    const unsigned long long ck = B.cand_cost[(size_t)axis * B.n + pos];
-    if (ck == NO_COST || ck != B.best_cost[s]) return;
-    atomicMin(&B.best_idx[s], B.pos_of[B.sid[cur][axis][pos]] * 3u + axis);
+    unsigned long long ck = B.cand_cost[(size_t)axis * B.n_pad + pos];
+    if (ck == TIED) {
+        const uint32_t a = B.seg_a[cur][s], b = B.seg_b[cur][s];
+        const double* key = B.skey[cur][axis];
+        const uint32_t k = n_left_for(key + a, b - a, key[pos]);
+        if (!k) return;
+        ck = B.cand_cost[(size_t)axis * B.n_pad + a + k - 1u];
+    }
+    if (ck == NO_COST || ck != B.best_cost[cur][best_slot(s)]) return;
+    atomicMin(&B.best_idx[cur][s], B.pos_of[B.sid[cur][axis][pos]] * 3u + axis);
 }
 
 // EqualSize (partition.rs:229-248): buckets-1 planes per axis, evenly spaced
 // over the segment's box.  One thread per (segment, axis, plane).
 template <int PASS>
-__global__ void __launch_bounds__(BLOCK) k_candidates_equal_size(DBuild B, uint32_t cur, uint32_t n_seg) {
+__global__ void __launch_bounds__(BLOCK) k_candidates_equal_size(DBuild B, uint32_t cur, uint32_t level) {
+    const uint32_t n_seg = B.ctl[ctl_count(level)];
+    if (B.ctl[CTL_ERR] != 0u) return;
     const uint32_t per_axis = B.buckets - 1u, per_seg = 3u * per_axis;
     const unsigned long long t = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= (unsigned long long)n_seg * per_seg) return;
@@ -275,17 +789,8 @@ __global__ void __launch_bounds__(BLOCK) k_candidates_equal_size(DBuild B, uint3
     const uint32_t k = n_left_for(B.skey[cur][axis] + a, b - a, at);
     if (!k) return;
     const unsigned long long ck = ordered_key(cost_of_split(B, axis, a, b, k));
-    if (PASS == 0) atomicMin(&B.best_cost[s], ck);
-    else if (ck == B.best_cost[s]) atomicMin(&B.best_idx[s], idx);
-}
-
-__global__ void __launch_bounds__(BLOCK) k_reset_best(DBuild B, uint32_t n_seg) {
-    const uint32_t s = blockIdx.x * BLOCK + threadIdx.x;
-    if (s < n_seg) {
-        B.best_cost[s] = NO_COST;
-        B.best_idx[s] = NONE;
-    }
-    if (s == 0) B.ctl[0] = 0;
+    if (PASS == 0) atomicMin(&B.best_cost[cur][best_slot(s)], ck);
+    else if (ck == B.best_cost[cur][best_slot(s)]) atomicMin(&B.best_idx[cur][s], idx);
 }
 
 // longest_axis, partition.rs:28-40: max_by returns the last of equal maxima
@@ -299,18 +804,23 @@ __device__ __forceinline__ uint32_t longest_axis(const double* bb) {
 }
 
 // One thread per segment: fixes the split, writes the internal node and
-// opens the children (build_tree_rec, src/bvh/mod.rs:92-131).
-__global__ void __launch_bounds__(BLOCK) k_decide(DBuild B, uint32_t cur, uint32_t n_seg) {
+// opens the children (build_tree_rec, src/bvh/mod.rs:92-131).  The number of segments of a level lives on the device
+// (ctl[level & 3]); the host launches enough threads for the most a level can hold.
+__global__ void __launch_bounds__(BLOCK) k_decide(DBuild B, uint32_t cur, uint32_t level) {
     const uint32_t s = blockIdx.x * BLOCK + threadIdx.x;
-    if (s >= n_seg) return;
+    const uint32_t n_seg = B.ctl[ctl_count(level)];
+    if (s == 0u) B.ctl[ctl_count(level + 2u)] = 0u;   // neither read nor counted up at this level
+    if (s >= n_seg || B.ctl[CTL_ERR] != 0u) return;
     const uint32_t a = B.seg_a[cur][s], b = B.seg_b[cur][s], node = B.seg_node[cur][s], m = b - a;
-    const double* bb = B.L + (size_t)(b - 1u) * 6u;
+    // the segment's box: from the scan of the x order, or as the SAH passes folded it
+    const double* bb = B.L ? B.L + (size_t)(b - 1u) * 6u : B.seg_box + 6ull * s;
     uint32_t axis = 0, n_left = 0, strict = 0;
     double at = 0.0;
     // until decided otherwise: nothing moves and the segment has no children (the passes after this one also stop on an error)
     B.seg_axis[s] = 0;
     B.seg_plane[s] = 0.0;
     B.seg_nleft[s] = m;
+    B.seg_cut[s] = make_uint4(m, 0u, 0u, 0u);
     B.seg_child[0][s] = NONE;
     B.seg_child[1][s] = NONE;
     if (B.strategy == RTX_BISECT) {   // longest_axis_bisect_slice, partition.rs:58-68: sort on the axis, split in the middle
@@ -322,9 +832,9 @@ __global__ void __launch_bounds__(BLOCK) k_decide(DBuild B, uint32_t cur, uint32
         strict = 1;
         n_left = n_below(B.skey[cur][axis] + a, m, at);
     } else {
-        const uint32_t idx = B.best_idx[s];
+        const uint32_t idx = B.best_idx[cur][s];
         if (idx == NONE) {
-            atomicMax(&B.ctl[1], (uint32_t)ERR_NO_PLANE);
+            atomicMax(&B.ctl[CTL_ERR], (uint32_t)ERR_NO_PLANE);
             return;
         }
         if (B.strategy == RTX_SAH_PER_SURFACE) {
@@ -339,7 +849,7 @@ __global__ void __launch_bounds__(BLOCK) k_decide(DBuild B, uint32_t cur, uint32
         n_left = n_left_for(B.skey[cur][axis] + a, m, at);
     }
     if (n_left == 0u || n_left == m) {
-        atomicMax(&B.ctl[1], (uint32_t)ERR_EMPTY_SIDE);
+        atomicMax(&B.ctl[CTL_ERR], (uint32_t)ERR_EMPTY_SIDE);
         return;
     }
     const uint32_t node_r = node + 2u * n_left;
@@ -353,13 +863,25 @@ __global__ void __launch_bounds__(BLOCK) k_decide(DBuild B, uint32_t cur, uint32
     const uint32_t nxt = cur ^ 1u;
     uint32_t child[2] = {NONE, NONE};
     const uint32_t lo[2] = {a, a + n_left}, hi[2] = {a + n_left, b}, idx_of[2] = {node + 1u, node_r};
+    // segments of the next level: one atomic per wave
+    const bool opens[2] = {hi[0] - lo[0] >= 2u, hi[1] - lo[1] >= 2u};
+    const unsigned long long m0 = __ballot(opens[0]), m1 = __ballot(opens[1]), here = __ballot(1);
+    const uint32_t leader = (uint32_t)__ffsll((long long)here) - 1u, wanted = (uint32_t)(__popcll(m0) + __popcll(m1));
+    uint32_t slot = 0;
+    if (lane() == leader && wanted) slot = atomicAdd(&B.ctl[ctl_count(level + 1u)], wanted);
+    slot = __shfl(slot, leader);
+    const unsigned long long below = (1ull << lane()) - 1ull;
+    slot += (uint32_t)(__popcll(m0 & below) + __popcll(m1 & below));
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        if (hi[c] - lo[c] >= 2u) {
-            const uint32_t j = atomicAdd(&B.ctl[0], 1u);
+        if (opens[c]) {
+            const uint32_t j = slot++;
             B.seg_a[nxt][j] = lo[c];
             B.seg_b[nxt][j] = hi[c];
+            B.seg_rec[nxt][j] = make_uint4(lo[c], hi[c] - lo[c], 0u, 0u);
             B.seg_node[nxt][j] = idx_of[c];
+            B.best_cost[nxt][best_slot(j)] = NO_COST;
+            B.best_idx[nxt][j] = NONE;
             child[c] = j;
         } else {
             B.leaf_node[lo[c]] = idx_of[c];
@@ -368,6 +890,7 @@ __global__ void __launch_bounds__(BLOCK) k_decide(DBuild B, uint32_t cur, uint32
     B.seg_axis[s] = axis;
     B.seg_plane[s] = at;
     B.seg_nleft[s] = n_left | (strict << 31);
+    B.seg_cut[s] = make_uint4(n_left | (strict << 31), axis, (uint32_t)__double2loint(at), (uint32_t)__double2hiint(at));
     B.seg_child[0][s] = child[0];
     B.seg_child[1][s] = child[1];
 }
@@ -377,70 +900,128 @@ __device__ __forceinline__ bool passes(const DBuild& B, uint32_t axis, double at
     return strict ? c < at : c <= at;
 }
 
-__global__ void __launch_bounds__(BLOCK) k_flags(DBuild B, uint32_t cur) {
-    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
-    if (pos >= B.n) return;
-    const uint32_t s = B.seg_at[pos];
-    uint4 f = make_uint4(0, 0, 0, 0);
-    if (s != NONE && B.ctl[1] == 0u) {
-        const uint32_t axis = B.seg_axis[s], strict = B.seg_nleft[s] >> 31;
-        const double at = B.seg_plane[s];
-        f.x = passes(B, axis, at, strict, B.order[cur][pos]);
-        f.y = passes(B, axis, at, strict, B.sid[cur][0][pos]);
-        f.z = passes(B, axis, at, strict, B.sid[cur][1][pos]);
-        f.w = passes(B, axis, at, strict, B.sid[cur][2][pos]);
+// Splits the three sorted orders stably and lists the pairs that partition_in_place swaps in the surface order.  Where
+// an element goes follows from the number of passing elements of its segment before it: a segmented count over the four
+// lists, scanned in two passes like the boxes above (APPLY = false: predicates and tile totals; true: counts and moves).
+template <bool APPLY>
+__global__ void __launch_bounds__(BLOCK) k_split(DBuild B, uint32_t cur, uint32_t level, SCount* totals) {
+    __shared__ SCount lds[scan::WAVES];
+    if (B.ctl[ctl_count(level)] == 0u || B.ctl[CTL_ERR] != 0u) return;
+    constexpr uint32_t ITEMS = scan::ITEMS;
+    const CountOp op;
+    const uint32_t n = B.n, tile = blockIdx.x, n_tiles = gridDim.x, nxt = cur ^ 1u;
+    const uint32_t base = tile * TILE + threadIdx.x * ITEMS;
+    uint32_t sg[ITEMS + 2];
+    load_segments<ITEMS>(B, base, sg);
+    SCount x[ITEMS];
+    uint32_t bits[ITEMS];
+    static_assert(scan::ITEMS == 4, "the four flags of a thread's positions travel as one word");
+    uint32_t ids[4][ITEMS];   // the thread's entries of {order, sid[0], sid[1], sid[2]}
+    if (!APPLY) load_run<ITEMS>(B.order[cur], base, n, ids[0]);
+#pragma unroll
+    for (uint32_t ax = 0; ax < 3; ++ax) load_run<ITEMS>(B.sid[cur][ax], base, n, ids[ax + 1u]);
+    uint32_t packed = 0;
+    if (APPLY && base < n) packed = *reinterpret_cast<const uint32_t*>(B.flags + base);
+#pragma unroll
+    for (uint32_t i = 0; i < ITEMS; ++i) {
+        const uint32_t pos = base + i, s = sg[i + 1u];
+        bits[i] = 0;
+        x[i] = op.identity();
+        if (pos >= n) continue;
+        if (s == NONE) {
+            x[i].f = 1;
+            continue;
+        }
+        if (!APPLY) {
+            const uint4 cut = B.seg_cut[s];
+            const uint32_t axis = cut.y, strict = cut.x >> 31;
+            const double at = __hiloint2double((int)cut.w, (int)cut.z);
+            bits[i] = (uint32_t)passes(B, axis, at, strict, ids[0][i]);
+            // the list sorted on the split axis holds its key next to the surface: no look-up of the centroid
+            const double own_key = B.skey[cur][axis][pos];
+#pragma unroll
+            for (uint32_t ax = 0; ax < 3; ++ax) {
+                const bool pass = ax == axis ? (strict ? own_key < at : own_key <= at) : passes(B, axis, at, strict, ids[ax + 1u][i]);
+                bits[i] |= (uint32_t)pass << (ax + 1u);
+            }
+            packed |= bits[i] << (8u * i);
+        } else {
+            bits[i] = (packed >> (8u * i)) & 0xFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[i].c[k] = (bits[i] >> k) & 1u;
+        x[i].f = sg[i] != s;
     }
-    B.flags[pos] = f;
-}
-
-// Splits the three sorted orders stably and lists the pairs that
-// partition_in_place swaps in the surface order.
-__global__ void __launch_bounds__(BLOCK) k_scatter(DBuild B, uint32_t cur) {
-    const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
-    if (pos >= B.n || B.ctl[1] != 0u) return;
-    const uint32_t nxt = cur ^ 1u;
-    const uint32_t s = B.seg_at[pos];
-    if (s == NONE) {
+    SCount total;
+    if (!APPLY) {
+        if (base < n) *reinterpret_cast<uint32_t*>(B.flags + base) = packed;   // (padded like every table)
+        block_scan_dir<false, ITEMS>(op, x, op.identity(), lds, total);
+        if (threadIdx.x == 0) totals[tile] = total;
+        return;
+    }
+    const SCount carry = scan::look_back<false>(op, totals, tile, n_tiles, lds);
+    block_scan_dir<false, ITEMS>(op, x, carry, lds, total);
+    double keys[3][ITEMS];
+#pragma unroll
+    for (uint32_t ax = 0; ax < 3; ++ax) {
+        const double* key = B.skey[cur][ax];
+        if (base + ITEMS <= n) {
+            const double2 k01 = *reinterpret_cast<const double2*>(key + base), k23 = *reinterpret_cast<const double2*>(key + base + 2u);
+            keys[ax][0] = k01.x; keys[ax][1] = k01.y; keys[ax][2] = k23.x; keys[ax][3] = k23.y;
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < ITEMS; ++i) keys[ax][i] = base + i < n ? key[base + i] : 0.0;
+        }
+    }
+    uint32_t passed[ITEMS] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t i = 0; i < ITEMS; ++i) {
+        const uint32_t pos = base + i, s = sg[i + 1u];
+        if (pos >= n || s == NONE) continue;
+        const uint4 rec = B.seg_rec[cur][s];
+        const uint32_t a = rec.x, b = a + rec.y, n_left = B.seg_cut[s].x & 0x7FFFFFFFu, r = pos - a;
+        // The split position comes from a search in the sorted keys, the counts from the predicate: they agree for
+        // finite keys.  Nothing is written outside the segment if they ever do not; the build then fails.
+        if (sg[i + 2u] != s && (x[i].c[0] != n_left || x[i].c[1] != n_left || x[i].c[2] != n_left || x[i].c[3] != n_left))
+            atomicMax(&B.ctl[CTL_ERR], (uint32_t)ERR_INTERNAL);
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            B.sid[nxt][ax][pos] = B.sid[cur][ax][pos];
-            B.skey[nxt][ax][pos] = B.skey[cur][ax][pos];
+            const uint32_t passing = (bits[i] >> (ax + 1)) & 1u, before = x[i].c[ax + 1] - passing;
+            uint32_t to = passing ? a + before : a + n_left + (r - before);
+            to = to < b ? to : b - 1u;
+            B.sid[nxt][ax][to] = ids[ax + 1][i];
+            B.skey[nxt][ax][to] = keys[ax][i];
         }
-        return;
+        const uint32_t passing = bits[i] & 1u, passed_before = x[i].c[0] - passing;
+        passed[i] = passed_before;
+        if (pos < a + n_left) {
+            if (!passing) B.F[a + (r - passed_before < b - a ? r - passed_before : 0u)] = pos;
+        } else if (passing) {
+            const uint32_t j = n_left - (passed_before + 1u);
+            B.G[a + (j < b - a ? j : 0u)] = pos;
+        }
     }
-    const uint32_t a = B.seg_a[cur][s], b = B.seg_b[cur][s], n_left = B.seg_nleft[s] & 0x7FFFFFFFu, r = pos - a;
-    const uint4 f = B.flags[pos], p = B.P[pos], pa = B.P[a], pb = B.P[b];
-    // The split position comes from a search in the sorted keys, the flags from the predicate: they agree for
-    // finite keys.  Nothing is written outside the segment if they ever do not; the build then fails.
-    if (pb.x - pa.x != n_left || pb.y - pa.y != n_left || pb.z - pa.z != n_left || pb.w - pa.w != n_left) {
-        atomicMax(&B.ctl[1], (uint32_t)ERR_INTERNAL);
-        return;
-    }
-    const uint32_t fl[3] = {f.y, f.z, f.w}, before[3] = {p.y - pa.y, p.z - pa.z, p.w - pa.w};
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-        const uint32_t to = fl[ax] ? a + before[ax] : a + n_left + (r - before[ax]);
-        B.sid[nxt][ax][to] = B.sid[cur][ax][pos];
-        B.skey[nxt][ax][to] = B.skey[cur][ax][pos];
-    }
-    const uint32_t passed_before = p.x - pa.x;
-    if (pos < a + n_left) {
-        if (!f.x) B.F[a + (r - passed_before)] = pos;
-    } else if (f.x) {
-        B.G[a + (n_left - (passed_before + 1u))] = pos;
-    }
+    if (base < n) *reinterpret_cast<uint4*>(B.before + base) = make_uint4(passed[0], passed[1], passed[2], passed[3]);
 }
 
-// The surface order after partition_in_place, and the segment of every position at the next level.
-__global__ void __launch_bounds__(BLOCK) k_reorder(DBuild B, uint32_t cur) {
+// what the host reads after a level
+__device__ __forceinline__ void report_level(const DBuild& B, uint32_t level) {
+    B.report[0] = B.ctl[ctl_count(level)];
+    B.report[1] = B.ctl[ctl_count(level + 1u)];
+    B.report[2] = B.ctl[CTL_ERR];
+}
+// The surface order after partition_in_place, and the segment of every position at the next level.  Runs at every level
+// the host enqueues, also one past the last: the order moves to the other buffer either way.
+__global__ void __launch_bounds__(BLOCK) k_reorder(DBuild B, uint32_t cur, uint32_t level) {
     const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
-    if (pos >= B.n || B.ctl[1] != 0u) return;
+    if (pos == 0u) report_level(B, level);
+    if (pos >= B.n || B.ctl[CTL_ERR] != 0u) return;
     const uint32_t nxt = cur ^ 1u;
     const uint32_t s = B.seg_at[pos];
     uint32_t from = pos;
     if (s != NONE) {
         const uint32_t a = B.seg_a[cur][s], n_left = B.seg_nleft[s] & 0x7FFFFFFFu, r = pos - a;
-        const uint32_t passed_before = B.P[pos].x - B.P[a].x, f = B.flags[pos].x;
+        const uint32_t passed_before = B.before[pos], f = B.flags[pos] & 1u;
         if (pos < a + n_left) {
             if (!f) from = B.G[a + (r - passed_before)];
         } else if (f) {
@@ -462,19 +1043,24 @@ __global__ void __launch_bounds__(BLOCK) k_reorder(DBuild B, uint32_t cur) {
 __global__ void __launch_bounds__(BLOCK) k_bisect_coordinate_keys(DBuild B, uint32_t cur, unsigned long long* keys) {
     const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
     if (pos >= B.n) return;
-    const uint32_t s = B.seg_at[pos];
+    const uint32_t s = B.ctl[CTL_ERR] != 0u ? NONE : B.seg_at[pos];
     keys[pos] = s == NONE ? 0ull : ordered_key(B.box[6ull * B.order[cur][pos] + B.seg_axis[s]]);
 }
 __global__ void __launch_bounds__(BLOCK) k_bisect_segment_keys(DBuild B, uint32_t cur, const uint32_t* by_coordinate, uint32_t* keys) {
     const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
     if (j >= B.n) return;
+    if (B.ctl[CTL_ERR] != 0u) {
+        keys[j] = j;
+        return;
+    }
     const uint32_t pos = B.pos_of[by_coordinate[j]];
     const uint32_t s = B.seg_at[pos];
     keys[j] = s == NONE ? pos : B.seg_a[cur][s];
 }
-__global__ void __launch_bounds__(BLOCK) k_bisect_finish(DBuild B, uint32_t cur) {
+__global__ void __launch_bounds__(BLOCK) k_bisect_finish(DBuild B, uint32_t cur, uint32_t level) {
     const uint32_t pos = blockIdx.x * BLOCK + threadIdx.x;
-    if (pos >= B.n) return;
+    if (pos == 0u) report_level(B, level);
+    if (pos >= B.n || B.ctl[CTL_ERR] != 0u) return;
     B.pos_of[B.order[cur ^ 1u][pos]] = pos;
     const uint32_t s = B.seg_at[pos];
     if (s != NONE) B.seg_at[pos] = B.seg_child[pos < B.seg_a[cur][s] + (B.seg_nleft[s] & 0x7FFFFFFFu) ? 0 : 1][s];
@@ -498,9 +1084,12 @@ __global__ void __launch_bounds__(BLOCK) k_init(DBuild B, unsigned long long* so
     if (i == 0) {
         B.seg_a[0][0] = 0;
         B.seg_b[0][0] = B.n;
+        B.seg_rec[0][0] = make_uint4(0u, B.n, 0u, 0u);
         B.seg_node[0][0] = 0;
-        B.ctl[0] = 0;
-        B.ctl[1] = 0;
+        B.best_cost[0][0] = NO_COST;
+        B.best_idx[0][0] = NONE;
+        for (uint32_t k = 0; k < CTL_WORDS; ++k) B.ctl[k] = 0;
+        B.ctl[ctl_count(0)] = B.n >= 2u ? 1u : 0u;   // the root is the one segment of level 0
     }
 }
 __global__ void __launch_bounds__(BLOCK) k_sorted_keys(DBuild B) {
@@ -522,7 +1111,6 @@ __global__ void __launch_bounds__(BLOCK) k_leaves(DBuild B, uint32_t cur) {
         B.node_bmax[(size_t)k * B.n_nodes + node] = b[3 + k];
     }
 }
-
 // ---------------------------------------------------------------- host side
 struct Arena {
     char* base = nullptr;
@@ -542,7 +1130,7 @@ struct Plan {
     unsigned long long* sort_keys_out;
     uint32_t* sort_vals;
     SBox* box_totals;
-    uint4* flag_totals;
+    SCount* count_totals;
     void* sort_tmp;
     size_t sort_tmp_bytes;
 };
@@ -563,22 +1151,29 @@ void carve(Arena& ar, Plan& p, uint32_t n, size_t sort_tmp_bytes) {
         B.seg_b[c] = ar.take<uint32_t>(n);
         B.seg_node[c] = ar.take<uint32_t>(n);
         B.seg_child[c] = ar.take<uint32_t>(n);
+        B.seg_rec[c] = ar.take<uint4>(n);
+        B.best_cost[c] = ar.take<unsigned long long>((size_t)n + BEST_EXTRA);
+        B.best_idx[c] = ar.take<uint32_t>(n);
     }
     B.pos_of = ar.take<uint32_t>(n);
     B.seg_at = ar.take<uint32_t>(n);
+    B.seg_cut = ar.take<uint4>(n);
     B.seg_axis = ar.take<uint32_t>(n);
     B.seg_plane = ar.take<double>(n);
     B.seg_nleft = ar.take<uint32_t>(n);
-    B.best_cost = ar.take<unsigned long long>(n);
-    B.best_idx = ar.take<uint32_t>(n);
-    B.cand_cost = ar.take<unsigned long long>(3ull * n);
-    B.L = ar.take<double>(18ull * n);
-    B.R = ar.take<double>(18ull * n);
-    B.flags = ar.take<uint4>(n);
-    B.P = ar.take<uint4>((size_t)n + 1u);
+    B.cand_cost = ar.take<unsigned long long>(3ull * B.n_pad);
+    // scanned boxes in memory: the x order forward for the strategies that split by the segment's box, all six for the
+    // planes of EqualSize, none for PerSurface
+    const bool per_surface = B.strategy == RTX_SAH_PER_SURFACE, equal_size = B.strategy == RTX_SAH_EQUAL_SIZE;
+    B.L = per_surface ? nullptr : ar.take<double>((equal_size ? 18ull : 6ull) * n);
+    B.R = equal_size ? ar.take<double>(18ull * n) : nullptr;
+    B.flags = ar.take<uint8_t>(n);
+    B.before = ar.take<uint32_t>(n);
     B.F = ar.take<uint32_t>(n);
     B.G = ar.take<uint32_t>(n);
-    B.ctl = ar.take<uint32_t>(2);
+    B.ctl = ar.take<uint32_t>(CTL_WORDS);
+    B.report = ar.take<uint32_t>(REPORT_WORDS);
+    B.seg_box = per_surface ? ar.take<double>(6ull * n) : nullptr;
     B.leaf_node = ar.take<uint32_t>(n);
     B.node_right = ar.take<uint32_t>(B.n_nodes);
     B.node_prim = ar.take<uint32_t>(B.n_nodes);
@@ -587,8 +1182,8 @@ void carve(Arena& ar, Plan& p, uint32_t n, size_t sort_tmp_bytes) {
     p.sort_keys_in = ar.take<unsigned long long>(3ull * n);
     p.sort_keys_out = ar.take<unsigned long long>(n);
     p.sort_vals = ar.take<uint32_t>(n);
-    p.box_totals = ar.take<SBox>(6ull * n_tiles);
-    p.flag_totals = ar.take<uint4>(n_tiles);
+    p.box_totals = ar.take<SBox>(6ull * ((n + SAH_TILE - 1u) / SAH_TILE > n_tiles ? (n + SAH_TILE - 1u) / SAH_TILE : n_tiles));
+    p.count_totals = ar.take<SCount>(n_tiles);
     p.sort_tmp = ar.take<char>(sort_tmp_bytes);
     p.sort_tmp_bytes = sort_tmp_bytes;
 }
@@ -605,6 +1200,11 @@ void carve(Arena& ar, Plan& p, uint32_t n, size_t sort_tmp_bytes) {
 
 }  // namespace build
 
+// How many levels the host enqueues beyond the last one whose segment count it has seen.  The device keeps the segment
+// counts; the host reads a level's report two levels late, so the stream never runs dry while it waits, and a tree that
+// is complete costs one level of launches that find nothing to do.
+constexpr uint32_t LEVELS_AHEAD = 2, REPORT_RING = 8;
+
 int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_t buckets, uint32_t* leaf_order, double* node_bmin,
                      double* node_bmax, uint32_t* node_right, uint32_t* node_prim, rtx_build_stats* stats, std::string& msg) {
     using namespace build;
@@ -614,13 +1214,28 @@ int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_
     Arena ar;
     hipStream_t st = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    uint32_t cur = 0, n_seg = n >= 2u ? 1u : 0u, levels = 0;
-    const uint32_t grid = (n + BLOCK - 1u) / BLOCK;
+    hipEvent_t level_done[REPORT_RING] = {};
+    uint32_t* report = nullptr;   // pinned, REPORT_RING copies of the level report
+    std::vector<uint32_t> level_segments;   // segments (= internal nodes) of every level whose report has been read
+    uint32_t cur = 0, level = 0, err = 0;
+    const uint32_t grid = (n + BLOCK - 1u) / BLOCK, n_tiles = (n + TILE - 1u) / TILE;
     size_t sort_tmp_bytes = 0;
     DBuild& B = plan.B;
-    uint32_t host_ctl[2] = {0, 0};
+    bool complete = n < 2u;
+    // waits for the report of the next level not yet read; false once that level turns out to be the last (or failed)
+    auto read_report = [&](hipError_t& e) -> bool {
+        const uint32_t seen = (uint32_t)level_segments.size();
+        e = hipEventSynchronize(level_done[seen % REPORT_RING]);
+        if (e != hipSuccess) return false;
+        const uint32_t* r = report + (size_t)(seen % REPORT_RING) * REPORT_WORDS;
+        level_segments.push_back(r[0]);
+        err = r[2];
+        complete = r[1] == 0u;
+        return err == 0u && !complete;
+    };
 
     B.n = n;
+    B.n_pad = (n + 3u) & ~3u;
     B.strategy = (uint32_t)strategy;
     B.buckets = buckets;
     B.n_nodes = 2u * n - 1u;
@@ -637,8 +1252,13 @@ int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_
     BUILD_TRY(hipMalloc((void**)&ar.base, ar.size));
     ar.used = 0;
     carve(ar, plan, n, sort_tmp_bytes);
+    BUILD_TRY(hipHostMalloc((void**)&report, REPORT_RING * REPORT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
     for (auto& e : ev) BUILD_TRY(hipEventCreate(&e));
+    for (auto& e : level_done) BUILD_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     BUILD_TRY(hipEventRecord(ev[0], st));
+    // Every table starts as zeros: a level that the host enqueues after one that failed reads tables the failed level never
+    // wrote, and although its kernels look at the error word first, no index in them may ever come from stale memory.
+    BUILD_TRY(hipMemsetAsync(ar.base, 0, ar.size, st));
     BUILD_TRY(hipMemcpyAsync(const_cast<double*>(B.box), leaf_boxes, 6ull * n * sizeof(double), hipMemcpyHostToDevice, st));
 
     hipLaunchKernelGGL(k_init, dim3(grid), dim3(BLOCK), 0, st, B, plan.sort_keys_in, plan.sort_vals);
@@ -650,22 +1270,44 @@ int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_
     }
     BUILD_TRY(hipEventRecord(ev[1], st));
 
-    while (n_seg > 0u) {
-        const uint32_t seg_grid = (n_seg + BLOCK - 1u) / BLOCK;
-        BoxScan box_scan{B, cur};
-        // a midpoint split needs the segment boxes only (x order, forward); the SAH needs all six folds
-        run_scan(box_scan, n, strategy == RTX_MIDPOINT || strategy == RTX_BISECT ? 1u : 6u, plan.box_totals, st);
-        hipLaunchKernelGGL(k_reset_best, dim3(seg_grid), dim3(BLOCK), 0, st, B, n_seg);
-        if (strategy == RTX_SAH_PER_SURFACE) {
-            hipLaunchKernelGGL(k_candidates_per_surface, dim3(grid, 3), dim3(BLOCK), 0, st, B, cur);
-            hipLaunchKernelGGL(k_pick_per_surface, dim3(grid, 3), dim3(BLOCK), 0, st, B, cur);
-        } else if (strategy == RTX_SAH_EQUAL_SIZE) {
-            const unsigned long long threads = (unsigned long long)n_seg * 3ull * (buckets - 1u);
-            const uint32_t cand_grid = (uint32_t)((threads + BLOCK - 1u) / BLOCK);
-            hipLaunchKernelGGL(k_candidates_equal_size<0>, dim3(cand_grid), dim3(BLOCK), 0, st, B, cur, n_seg);
-            hipLaunchKernelGGL(k_candidates_equal_size<1>, dim3(cand_grid), dim3(BLOCK), 0, st, B, cur, n_seg);
+    while (!complete && err == 0u) {
+        if (level > n) {   // a tree over n surfaces has fewer levels than that
+            msg = "rtx_bvh_build: the device never reported the last level";
+            code = RTX_ERR_BUILD;
+            goto done;
         }
-        hipLaunchKernelGGL(k_decide, dim3(seg_grid), dim3(BLOCK), 0, st, B, cur, n_seg);
+        if (level >= LEVELS_AHEAD) {
+            hipError_t e = hipSuccess;
+            const bool go_on = read_report(e);
+            BUILD_TRY(e);
+            if (!go_on) break;
+        }
+        // a level holds at most 2^level segments, and no more than n/2 (a segment has two surfaces or more)
+        const uint32_t seg_bound = level < 31u && (1u << level) < n / 2u ? 1u << level : n / 2u;
+        const uint32_t seg_grid = (seg_bound + BLOCK - 1u) / BLOCK;
+        if (strategy == RTX_SAH_PER_SURFACE) {
+            const uint32_t sah_tiles = (n + SAH_TILE - 1u) / SAH_TILE;
+            hipLaunchKernelGGL((k_sah_per_surface<false, false>), dim3(sah_tiles, 3), dim3(BLOCK), 0, st, B, cur, level, plan.box_totals);
+            if ((n >> (level < 31u ? level : 31u)) >= SAH_TILE) {   // segments of this level span tiles, on average
+                hipLaunchKernelGGL(k_box_spine, dim3(6), dim3(BLOCK), 0, st, sah_tiles, plan.box_totals);
+                hipLaunchKernelGGL(k_segment_areas, dim3(seg_grid), dim3(BLOCK), 0, st, B, cur, level, plan.box_totals, 1u);
+                hipLaunchKernelGGL((k_sah_per_surface<true, true>), dim3(sah_tiles, 3), dim3(BLOCK), 0, st, B, cur, level, plan.box_totals);
+            } else {
+                hipLaunchKernelGGL(k_segment_areas, dim3(seg_grid), dim3(BLOCK), 0, st, B, cur, level, plan.box_totals, 0u);
+                hipLaunchKernelGGL((k_sah_per_surface<true, false>), dim3(sah_tiles, 3), dim3(BLOCK), 0, st, B, cur, level, plan.box_totals);
+            }
+            hipLaunchKernelGGL(k_pick_per_surface, dim3(grid, 3), dim3(BLOCK), 0, st, B, cur, level);
+        } else {
+            // a midpoint split needs the segment boxes only (x order, forward); the planes of EqualSize need all six folds
+            run_scan(BoxScan{B, cur}, n, strategy == RTX_SAH_EQUAL_SIZE ? 6u : 1u, plan.box_totals, st);
+            if (strategy == RTX_SAH_EQUAL_SIZE) {
+                const unsigned long long threads = (unsigned long long)seg_bound * 3ull * (buckets - 1u);
+                const uint32_t cand_grid = (uint32_t)((threads + BLOCK - 1u) / BLOCK);
+                hipLaunchKernelGGL(k_candidates_equal_size<0>, dim3(cand_grid), dim3(BLOCK), 0, st, B, cur, level);
+                hipLaunchKernelGGL(k_candidates_equal_size<1>, dim3(cand_grid), dim3(BLOCK), 0, st, B, cur, level);
+            }
+        }
+        hipLaunchKernelGGL(k_decide, dim3(seg_grid), dim3(BLOCK), 0, st, B, cur, level);
         if (strategy == RTX_BISECT) {
             hipLaunchKernelGGL(k_bisect_coordinate_keys, dim3(grid), dim3(BLOCK), 0, st, B, cur, plan.sort_keys_in);
             BUILD_TRY((hipError_t)rocprim::radix_sort_pairs(plan.sort_tmp, plan.sort_tmp_bytes, plan.sort_keys_in, plan.sort_keys_out, B.order[cur],
@@ -673,26 +1315,31 @@ int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_
             hipLaunchKernelGGL(k_bisect_segment_keys, dim3(grid), dim3(BLOCK), 0, st, B, cur, plan.sort_vals, B.F);
             BUILD_TRY((hipError_t)rocprim::radix_sort_pairs(plan.sort_tmp, plan.sort_tmp_bytes, B.F, B.G, plan.sort_vals, B.order[cur ^ 1u], n, 0,
                                                            32, st));
-            hipLaunchKernelGGL(k_bisect_finish, dim3(grid), dim3(BLOCK), 0, st, B, cur);
+            hipLaunchKernelGGL(k_bisect_finish, dim3(grid), dim3(BLOCK), 0, st, B, cur, level);
         } else {
-            hipLaunchKernelGGL(k_flags, dim3(grid), dim3(BLOCK), 0, st, B, cur);
-            run_scan(FlagScan{B}, n, 1u, plan.flag_totals, st);
-            hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(BLOCK), 0, st, B, cur);
-            hipLaunchKernelGGL(k_reorder, dim3(grid), dim3(BLOCK), 0, st, B, cur);
+            hipLaunchKernelGGL(k_split<false>, dim3(n_tiles), dim3(BLOCK), 0, st, B, cur, level, plan.count_totals);
+            hipLaunchKernelGGL(k_split<true>, dim3(n_tiles), dim3(BLOCK), 0, st, B, cur, level, plan.count_totals);
+            hipLaunchKernelGGL(k_reorder, dim3(grid), dim3(BLOCK), 0, st, B, cur, level);
         }
-        BUILD_TRY(hipMemcpyAsync(host_ctl, B.ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
-        BUILD_TRY(hipStreamSynchronize(st));
-        if (host_ctl[1] != 0u) {
-            // the reference panics with this message (partition.rs:219) or, for an empty side, indexes out of range / never returns
-            msg = host_ctl[1] == ERR_NO_PLANE     ? "No valid splitting plane"
-                  : host_ctl[1] == ERR_EMPTY_SIDE ? "partition left one side empty"
-                                                  : "rtx_bvh_build: split position and predicate disagree";
-            code = RTX_ERR_BUILD;
-            goto done;
-        }
-        n_seg = host_ctl[0];
+        BUILD_TRY(hipMemcpyAsync(report + (size_t)(level % REPORT_RING) * REPORT_WORDS, B.report, REPORT_WORDS * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, st));
+        BUILD_TRY(hipEventRecord(level_done[level % REPORT_RING], st));
         cur ^= 1u;
-        ++levels;
+        ++level;
+    }
+    // the levels enqueued after the last report read: they hold no segments, unless the tree is shallower than LEVELS_AHEAD
+    while (err == 0u && level_segments.size() < level) {
+        hipError_t e = hipSuccess;
+        (void)read_report(e);
+        BUILD_TRY(e);
+    }
+    if (err != 0u) {
+        // the reference panics with this message (partition.rs:219) or, for an empty side, indexes out of range / never returns
+        msg = err == ERR_NO_PLANE     ? "No valid splitting plane"
+              : err == ERR_EMPTY_SIDE ? "partition left one side empty"
+                                      : "rtx_bvh_build: split position and predicate disagree";
+        code = RTX_ERR_BUILD;
+        goto done;
     }
     hipLaunchKernelGGL(k_leaves, dim3(grid), dim3(BLOCK), 0, st, B, cur);
     BUILD_TRY(hipEventRecord(ev[2], st));
@@ -707,6 +1354,8 @@ int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_
         float ms_sort = 0.f, ms_levels = 0.f;
         BUILD_TRY(hipEventElapsedTime(&ms_sort, ev[0], ev[1]));
         BUILD_TRY(hipEventElapsedTime(&ms_levels, ev[1], ev[2]));
+        uint32_t levels = 0;
+        for (uint32_t c : level_segments) levels += c != 0u;
         stats->levels = levels;
         stats->n_nodes = B.n_nodes;
         stats->ms_sort = ms_sort;
@@ -714,8 +1363,12 @@ int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_
         stats->device_bytes = ar.size;
     }
 done:
+    if (ar.base) (void)hipStreamSynchronize(st);   // nothing of this call is still running when its tables go
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : level_done)
+        if (e) (void)hipEventDestroy(e);
+    if (report) (void)hipHostFree(report);
     if (ar.base) (void)hipFree(ar.base);
     return code;
 }

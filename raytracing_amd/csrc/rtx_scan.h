@@ -52,6 +52,64 @@ __device__ __forceinline__ void block_scan(const Op& op, T (&x)[N], const T& car
     __syncthreads();
 }
 
+// The same scan in either direction.  REV: the scan runs from the block's last element to its first (thread BLOCK-1 before
+// thread 0, x[N-1] before x[0]); `carry` is what lies beyond the block on the side the scan comes from.
+__device__ __forceinline__ uint32_t shfl_down_t(const uint32_t& x, uint32_t d) { return __shfl_down(x, d); }
+template <bool REV, uint32_t N, class Op, class T>
+__device__ __forceinline__ void block_scan_dir(const Op& op, T (&x)[N], const T& carry, T* lds, T& total) {
+    if (!REV) {
+#pragma unroll
+        for (uint32_t i = 1; i < N; ++i) x[i] = op.combine(x[i - 1], x[i]);
+    } else {
+#pragma unroll
+        for (uint32_t i = N - 1; i > 0; --i) x[i - 1] = op.combine(x[i], x[i - 1]);
+    }
+    T inc = REV ? x[0] : x[N - 1];
+    const uint32_t rank = REV ? 63u - lane() : lane();   // position of the lane in scan order
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const T prev = REV ? shfl_down_t(inc, d) : shfl_up_t(inc, d);
+        if (rank >= d) inc = op.combine(prev, inc);
+    }
+    const uint32_t wave = threadIdx.x >> 6, wrank = REV ? WAVES - 1u - wave : wave;
+    if (rank == 63) lds[wrank] = inc;
+    __syncthreads();
+    T prefix = carry;
+    total = carry;
+#pragma unroll
+    for (uint32_t w = 0; w < WAVES; ++w) {
+        if (w < wrank) prefix = op.combine(prefix, lds[w]);
+        total = op.combine(total, lds[w]);
+    }
+    const T before = REV ? shfl_down_t(inc, 1) : shfl_up_t(inc, 1);
+    if (rank > 0) prefix = op.combine(prefix, before);
+#pragma unroll
+    for (uint32_t i = 0; i < N; ++i) x[i] = op.combine(prefix, x[i]);
+    __syncthreads();
+}
+
+// What a segmented scan carries into tile `tile` of a row of tile totals: the fold of the totals before it (REV: after it),
+// from the nearest total that holds a segment start on.  T::f != 0 marks such a total.  Whole block; the result is uniform.
+template <bool REV, class Op, class T>
+__device__ __forceinline__ T look_back(const Op& op, const T* row, uint32_t tile, uint32_t n_tiles, T* lds) {
+    T acc = op.identity();
+    const uint32_t avail = REV ? n_tiles - 1u - tile : tile;
+    if (avail == 0u) return acc;
+    acc = row[REV ? tile + 1u : tile - 1u];   // deep in the tree every tile holds a segment start: the neighbour is all there is
+    if (acc.f) return acc;
+    acc = op.identity();
+    for (uint32_t done = 0; done < avail; done += BLOCK) {
+        const uint32_t j = done + threadIdx.x;   // distance from the tile, less one
+        T x[1];
+        x[0] = j < avail ? row[REV ? tile + 1u + j : tile - 1u - j] : op.identity();
+        T total;
+        block_scan_dir<true, 1>(op, x, op.identity(), lds, total);   // the farthest first
+        acc = op.combine(total, acc);
+        if (acc.f) break;
+    }
+    return acc;
+}
+
 // Three launches: tile totals, exclusive scan of the totals (one block per
 // row y), tiles again with their carry.  Op: T, identity(), load(i, y),
 // combine(a, b), store(i, y, inclusive).
