@@ -71,7 +71,7 @@ struct DBuild {
     uint32_t* seg_nleft;     // bit 31: predicate is `<` (midpoint) instead of `<=`
     uint32_t* seg_child[2];  // segment index of the left / right child at the next level, NONE for a leaf
     unsigned long long* best_cost[2];   // by segment of this level / the next
-    uint32_t* best_idx[2];
+    unsigned long long* best_pick[2];   // the winning candidate: its place in the reference's order of candidates << 32 | surfaces left of its plane
     unsigned long long* cand_cost;   // [3][n]
     double* L;               // [3][n][6] box of the segment's sorted surfaces up to and including a position (not PerSurface)
     double* R;               // [3][n][6] ... from a position to the segment's end (EqualSize only)
@@ -449,17 +449,6 @@ __device__ __forceinline__ void load_segments(const DBuild& B, uint32_t base, ui
     sg[N + 1u] = base + N < n ? B.seg_at[base + N] : NONE;
 }
 
-// PerSurface (partition.rs:254-266): every surface's centroid coordinate on every axis is a candidate plane.  The cost of
-// the plane at a position of an axis' sorted order needs the box of the segment's surfaces up to that position and the box
-// of those behind it (left_of / right_of, partition.rs:136-166): a forward and a backward segmented scan of the boxes.
-// Neither scan is written to memory.  A block scans its tile both ways; a first pass (APPLY = false) leaves every tile's
-// totals and folds the box of every segment (the parent in the cost, partition.rs:93, and the node's box), the second
-// takes what the scans carry into the tile and prices its positions on the spot.  The carry comes from the totals: either
-// they have been scanned in between (SPINED, worth a launch while segments span many tiles) or the block folds the
-// totals next to it back to the nearest segment start.  Positions whose key equals the next one's share the plane, and
-// so the cost, of the last position of that run of equal keys (split_at, partition.rs:182-197): they are marked TIED and
-// looked up when the winner is picked.
-// totals: rows 0-2 forward per axis by tile, rows 3-5 backward per axis by tile counted from the end.
 #ifndef RTX_SAH_WAVES
 #define RTX_SAH_WAVES 4
 #endif
@@ -469,7 +458,8 @@ __device__ __forceinline__ void load_segments(const DBuild& B, uint32_t base, ui
 constexpr int SAH_WAVES = RTX_SAH_WAVES;   // waves per SIMD the register budget of the kernels below allows
 constexpr uint32_t SAH_ITEMS = RTX_SAH_ITEMS, SAH_TILE = BLOCK * SAH_ITEMS;   // positions per thread and per block
 
-// exclusive scan of every row of tile totals (one block per row); only the boxes of the result are used
+// exclusive scan of every row of tile totals (one block per row, eight totals per thread); only the boxes of the result are used
+constexpr uint32_t SPINE_ITEMS = 8, SPINE_TILE = BLOCK * SPINE_ITEMS;
 __global__ void __launch_bounds__(BLOCK) k_box_spine(uint32_t n_tiles, SBox* totals) {
     __shared__ double lds_v[scan::WAVES][6];
     __shared__ uint32_t lds_f[scan::WAVES];
@@ -480,53 +470,35 @@ __global__ void __launch_bounds__(BLOCK) k_box_spine(uint32_t n_tiles, SBox* tot
     if (threadIdx.x == 0) running[0] = BoxOp{}.identity();
     __syncthreads();
     uint32_t which = 0;
-    for (uint32_t first = 0; first < n_tiles; first += BLOCK, which ^= 1u) {
-        const uint32_t i = first + threadIdx.x;
-        double x[1][6];
+    for (uint32_t first = 0; first < n_tiles; first += SPINE_TILE, which ^= 1u) {
+        const uint32_t base = first + threadIdx.x * SPINE_ITEMS;
+        double x[SPINE_ITEMS][6];
         uint32_t starts = 0;
-        {
-            const SBox t = i < n_tiles ? row[i] : BoxOp{}.identity();
 #pragma unroll
-            for (int c = 0; c < 6; ++c) x[0][c] = t.v[c];
-            starts = t.f ? 1u : 0u;
+        for (uint32_t i = 0; i < SPINE_ITEMS; ++i) {
+            const SBox t = base + i < n_tiles ? row[base + i] : BoxOp{}.identity();
+#pragma unroll
+            for (int c = 0; c < 6; ++c) x[i][c] = t.v[c];
+            starts |= (t.f ? 1u : 0u) << i;
         }
-        block_scan_boxes<false, 1>(x, starts, running[which].v, &running[which ^ 1u], lds_v, lds_f);
-        // exclusive: the scan of the thread before
+        block_scan_boxes<false, SPINE_ITEMS>(x, starts, running[which].v, &running[which ^ 1u], lds_v, lds_f);
+        // exclusive: the scan one total back (the thread's own, the thread before's last, the wave before's, the carry)
         if (lane() == 63)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) edge[wave][c] = x[0][c];
+            for (int c = 0; c < 6; ++c) edge[wave][c] = x[SPINE_ITEMS - 1u][c];
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const double before = __shfl_up(x[0][c], 1);
-            const double excl = lane() > 0 ? before : (wave > 0 ? edge[wave - 1u][c] : running[which].v[c]);
-            if (i < n_tiles) row[i].v[c] = excl;
-        }
-        __syncthreads();
-    }
-}
-// What a scan carries into tile `tile` of a row of tile totals: the fold of the totals before it, from the nearest total
-// that holds a segment start on.  Returns where the box lies (null: nothing precedes); whole block, uniform.
-__device__ __forceinline__ const double* look_back_boxes(const SBox* row, uint32_t tile, SBox* acc, SBox* chunk, double (*lds_v)[6], uint32_t* lds_f) {
-    if (tile == 0u) return nullptr;
-    if (row[tile - 1u].f) return row[tile - 1u].v;   // deep in the tree every tile holds a segment start: the neighbour is all there is
-    if (threadIdx.x == 0) *acc = BoxOp{}.identity();
-    for (uint32_t done = 0; done < tile; done += BLOCK) {
-        const uint32_t j = done + threadIdx.x;   // distance from the tile, less one
-        double x[1][6];
-        uint32_t starts = 0;
-        {
-            const SBox t = j < tile ? row[tile - 1u - j] : BoxOp{}.identity();
+            const double before = __shfl_up(x[SPINE_ITEMS - 1u][c], 1);
+            double excl = lane() > 0 ? before : (wave > 0 ? edge[wave - 1u][c] : running[which].v[c]);
 #pragma unroll
-            for (int c = 0; c < 6; ++c) x[0][c] = t.v[c];
-            starts = t.f ? 1u : 0u;
+            for (uint32_t i = 0; i < SPINE_ITEMS; ++i) {
+                if (base + i < n_tiles) row[base + i].v[c] = excl;
+                excl = x[i][c];
+            }
         }
-        block_scan_boxes<true, 1>(x, starts, nullptr, chunk, lds_v, lds_f);   // the farthest first
-        if (threadIdx.x == 0) *acc = BoxOp{}.combine(*chunk, *acc);
         __syncthreads();
-        if (acc->f) break;
     }
-    return acc->v;
 }
 
 // PerSurface (partition.rs:254-266): every surface's centroid coordinate on every axis is a candidate plane.  The cost of
@@ -534,18 +506,15 @@ __device__ __forceinline__ const double* look_back_boxes(const SBox* row, uint32
 // of those behind it (left_of / right_of, partition.rs:136-166): a forward and a backward segmented scan of the boxes.
 // Neither scan is written to memory.  A block scans its tile both ways; a first pass (APPLY = false) leaves every tile's
 // totals and folds the box of every segment (the parent in the cost, partition.rs:93, and the node's box), the second
-// takes what the scans carry into the tile and prices its positions on the spot.  The carry comes from the totals: either
-// they have been scanned in between (SPINED, worth a launch while segments span many tiles) or the block folds the
-// totals next to it back to the nearest segment start.  Positions whose key equals the next one's share the plane, and
-// so the cost, of the last position of that run of equal keys (split_at, partition.rs:182-197): they are marked TIED and
-// looked up when the winner is picked.
+// takes what the scans carry into the tile (the totals, scanned in between by k_box_spine) and prices its positions on the
+// spot.  Positions whose key equals the next one's share the plane, and so the cost, of the last position of that run
+// of equal keys (split_at, partition.rs:182-197): they are marked TIED and looked up when the winner is picked.
 // totals: rows 0-2 forward per axis by tile, rows 3-5 backward per axis by tile counted from the end.
-template <bool APPLY, bool SPINED>
+template <bool APPLY>
 __global__ void __launch_bounds__(BLOCK, SAH_WAVES) k_sah_per_surface(DBuild B, uint32_t cur, uint32_t level, SBox* totals) {
     __shared__ double lds_v[scan::WAVES][6];
     __shared__ uint32_t lds_f[scan::WAVES];
     __shared__ double edge[scan::WAVES];
-    __shared__ SBox look[2];
     if (B.ctl[ctl_count(level)] == 0u || B.ctl[CTL_ERR] != 0u) return;
     constexpr uint32_t ITEMS = SAH_ITEMS;
     const uint32_t n = B.n, tile = blockIdx.x, axis = blockIdx.y, n_tiles = gridDim.x, tile_b = n_tiles - 1u - tile;
@@ -601,7 +570,7 @@ __global__ void __launch_bounds__(BLOCK, SAH_WAVES) k_sah_per_surface(DBuild B, 
         for (uint32_t i = 0; i < ITEMS; ++i)
 #pragma unroll
             for (int c = 0; c < 6; ++c) x[i][c] = raw[i][c];
-        const double* carry = SPINED ? row_b[tile_b].v : look_back_boxes(row_b, tile_b, &look[0], &look[1], lds_v, lds_f);
+        const double* carry = row_b[tile_b].v;
         block_scan_boxes<true, ITEMS>(x, ends, carry, nullptr, lds_v, lds_f);
         // ... the next item, the next thread's first, the carry
         const double own = area_factor(x[0]);
@@ -615,17 +584,13 @@ __global__ void __launch_bounds__(BLOCK, SAH_WAVES) k_sah_per_surface(DBuild B, 
             if (wave + 1u < scan::WAVES) {
                 nx = edge[wave + 1u];
             } else {
-                double beyond[6];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) beyond[c] = carry ? carry[c] : 0.0;
-                nx = area_factor(beyond);
+                nx = area_factor(carry);
             }
         }
         area_behind[ITEMS - 1u] = nx;
-        __syncthreads();   // (the carry may lie in `look`, which the next look-back overwrites)
     }
     {
-        const double* carry = SPINED ? row_f[tile].v : look_back_boxes(row_f, tile, &look[0], &look[1], lds_v, lds_f);
+        const double* carry = row_f[tile].v;
         block_scan_boxes<false, ITEMS>(raw, starts, carry, nullptr, lds_v, lds_f);
     }
 
@@ -726,9 +691,9 @@ __global__ void __launch_bounds__(BLOCK, SAH_WAVES) k_sah_per_surface(DBuild B, 
 }
 // Completes the box of every segment and notes its area factor (the parent in surface_area_heuristic, partition.rs:93)
 // next to the segment's first position and size: one 16-byte record for the pricing pass.  The first SAH pass left the
-// fold over the segment's positions in its last tile; the tiles before that one are in the totals of the x order
-// (totals scanned already if `spined`: then the entry of the last tile is all that precedes it in the segment).
-__global__ void __launch_bounds__(BLOCK) k_segment_areas(DBuild B, uint32_t cur, uint32_t level, const SBox* row_f, uint32_t spined) {
+// fold over the segment's positions in its last tile; what precedes that tile in the segment is the tile's entry in the
+// scanned totals of the x order.
+__global__ void __launch_bounds__(BLOCK) k_segment_areas(DBuild B, uint32_t cur, uint32_t level, const SBox* row_f) {
     const uint32_t s = blockIdx.x * BLOCK + threadIdx.x;
     if (s >= B.ctl[ctl_count(level)] || B.ctl[CTL_ERR] != 0u) return;
     const uint32_t a = B.seg_a[cur][s], b = B.seg_b[cur][s], tile_a = a / SAH_TILE, tile_e = (b - 1u) / SAH_TILE;
@@ -736,13 +701,11 @@ __global__ void __launch_bounds__(BLOCK) k_segment_areas(DBuild B, uint32_t cur,
 #pragma unroll
     for (int k = 0; k < 6; ++k) bb[k] = B.seg_box[6ull * s + k];
     if (tile_a < tile_e) {
-        for (uint32_t t = tile_e; t-- > (spined ? tile_e - 1u : tile_a);) {
-            const SBox& before = row_f[spined ? tile_e : t];
+        const SBox& before = row_f[tile_e];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                bb[k] = fmin(before.v[k], bb[k]);
-                bb[3 + k] = fmax(before.v[3 + k], bb[3 + k]);
-            }
+        for (int k = 0; k < 3; ++k) {
+            bb[k] = fmin(before.v[k], bb[k]);
+            bb[3 + k] = fmax(before.v[3 + k], bb[3 + k]);
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) B.seg_box[6ull * s + k] = bb[k];
@@ -759,15 +722,17 @@ __global__ void __launch_bounds__(BLOCK) k_pick_per_surface(DBuild B, uint32_t c
     const uint32_t s = B.seg_at[pos];
     if (s == NONE) return;
     unsigned long long ck = B.cand_cost[(size_t)axis * B.n_pad + pos];
+    uint32_t k = 0;   // surfaces left of the plane, once it is needed
     if (ck == TIED) {
         const uint32_t a = B.seg_a[cur][s], b = B.seg_b[cur][s];
         const double* key = B.skey[cur][axis];
-        const uint32_t k = n_left_for(key + a, b - a, key[pos]);
+        k = n_left_for(key + a, b - a, key[pos]);
         if (!k) return;
         ck = B.cand_cost[(size_t)axis * B.n_pad + a + k - 1u];
     }
     if (ck == NO_COST || ck != B.best_cost[cur][best_slot(s)]) return;
-    atomicMin(&B.best_idx[cur][s], B.pos_of[B.sid[cur][axis][pos]] * 3u + axis);
+    if (!k) k = pos + 1u - B.seg_a[cur][s];
+    atomicMin(&B.best_pick[cur][s], (unsigned long long)(B.pos_of[B.sid[cur][axis][pos]] * 3u + axis) << 32 | k);
 }
 
 // EqualSize (partition.rs:229-248): buckets-1 planes per axis, evenly spaced
@@ -790,7 +755,7 @@ __global__ void __launch_bounds__(BLOCK) k_candidates_equal_size(DBuild B, uint3
     if (!k) return;
     const unsigned long long ck = ordered_key(cost_of_split(B, axis, a, b, k));
     if (PASS == 0) atomicMin(&B.best_cost[cur][best_slot(s)], ck);
-    else if (ck == B.best_cost[cur][best_slot(s)]) atomicMin(&B.best_idx[cur][s], idx);
+    else if (ck == B.best_cost[cur][best_slot(s)]) atomicMin(&B.best_pick[cur][s], (unsigned long long)idx << 32 | k);
 }
 
 // longest_axis, partition.rs:28-40: max_by returns the last of equal maxima
@@ -832,21 +797,23 @@ __global__ void __launch_bounds__(BLOCK) k_decide(DBuild B, uint32_t cur, uint32
         strict = 1;
         n_left = n_below(B.skey[cur][axis] + a, m, at);
     } else {
-        const uint32_t idx = B.best_idx[cur][s];
-        if (idx == NONE) {
+        const unsigned long long pick = B.best_pick[cur][s];
+        if (pick == ~0ull) {
             atomicMax(&B.ctl[CTL_ERR], (uint32_t)ERR_NO_PLANE);
             return;
         }
+        const uint32_t idx = (uint32_t)(pick >> 32);
+        n_left = (uint32_t)pick;   // split_at for the winner's plane (partition.rs:182-197), worked out when it was priced
         if (B.strategy == RTX_SAH_PER_SURFACE) {
             axis = idx % 3u;
-            at = B.cen[(size_t)axis * B.n + B.order[cur][idx / 3u]];
+            // the winner's centroid coordinate: the key of the last surface on the left (equal keys share the plane)
+            at = n_left >= 1u && n_left < m ? B.skey[cur][axis][a + n_left - 1u] : 0.0;
         } else {
             const uint32_t per_axis = B.buckets - 1u;
             axis = idx / per_axis;
             const double step = (bb[3 + axis] - bb[axis]) / (double)B.buckets;
             at = bb[axis] + ((double)(idx % per_axis + 1u) * step);
         }
-        n_left = n_left_for(B.skey[cur][axis] + a, m, at);
     }
     if (n_left == 0u || n_left == m) {
         atomicMax(&B.ctl[CTL_ERR], (uint32_t)ERR_EMPTY_SIDE);
@@ -881,7 +848,7 @@ __global__ void __launch_bounds__(BLOCK) k_decide(DBuild B, uint32_t cur, uint32
             B.seg_rec[nxt][j] = make_uint4(lo[c], hi[c] - lo[c], 0u, 0u);
             B.seg_node[nxt][j] = idx_of[c];
             B.best_cost[nxt][best_slot(j)] = NO_COST;
-            B.best_idx[nxt][j] = NONE;
+            B.best_pick[nxt][j] = ~0ull;
             child[c] = j;
         } else {
             B.leaf_node[lo[c]] = idx_of[c];
@@ -1087,7 +1054,7 @@ __global__ void __launch_bounds__(BLOCK) k_init(DBuild B, unsigned long long* so
         B.seg_rec[0][0] = make_uint4(0u, B.n, 0u, 0u);
         B.seg_node[0][0] = 0;
         B.best_cost[0][0] = NO_COST;
-        B.best_idx[0][0] = NONE;
+        B.best_pick[0][0] = ~0ull;
         for (uint32_t k = 0; k < CTL_WORDS; ++k) B.ctl[k] = 0;
         B.ctl[ctl_count(0)] = B.n >= 2u ? 1u : 0u;   // the root is the one segment of level 0
     }
@@ -1133,56 +1100,60 @@ struct Plan {
     SCount* count_totals;
     void* sort_tmp;
     size_t sort_tmp_bytes;
+    size_t zeroed_bytes;   // the tables at the head of the arena that start as zeros
 };
 
 // Carves every table out of `ar`; with ar.base == nullptr only adds up the sizes.
 void carve(Arena& ar, Plan& p, uint32_t n, size_t sort_tmp_bytes) {
     DBuild& B = p.B;
-    const uint32_t n_tiles = (n + TILE - 1u) / TILE;
-    B.box = ar.take<double>(6ull * n);
-    B.cen = ar.take<double>(3ull * n);
+    const uint32_t n_tiles = (n + TILE - 1u) / TILE, sah_tiles = (n + SAH_TILE - 1u) / SAH_TILE;
+    const bool per_surface = B.strategy == RTX_SAH_PER_SURFACE, equal_size = B.strategy == RTX_SAH_EQUAL_SIZE;
+    // first the tables whose entries are used as positions, surface or segment numbers: they start as zeros (see the caller)
     for (int c = 0; c < 2; ++c) {
         B.order[c] = ar.take<uint32_t>(n);
-        for (int ax = 0; ax < 3; ++ax) {
-            B.sid[c][ax] = ar.take<uint32_t>(n);
-            B.skey[c][ax] = ar.take<double>(n);
-        }
+        for (int ax = 0; ax < 3; ++ax) B.sid[c][ax] = ar.take<uint32_t>(n);
         B.seg_a[c] = ar.take<uint32_t>(n);
         B.seg_b[c] = ar.take<uint32_t>(n);
         B.seg_node[c] = ar.take<uint32_t>(n);
         B.seg_child[c] = ar.take<uint32_t>(n);
         B.seg_rec[c] = ar.take<uint4>(n);
-        B.best_cost[c] = ar.take<unsigned long long>((size_t)n + BEST_EXTRA);
-        B.best_idx[c] = ar.take<uint32_t>(n);
+        B.best_pick[c] = ar.take<unsigned long long>(n);
     }
     B.pos_of = ar.take<uint32_t>(n);
     B.seg_at = ar.take<uint32_t>(n);
     B.seg_cut = ar.take<uint4>(n);
     B.seg_axis = ar.take<uint32_t>(n);
-    B.seg_plane = ar.take<double>(n);
     B.seg_nleft = ar.take<uint32_t>(n);
-    B.cand_cost = ar.take<unsigned long long>(3ull * B.n_pad);
-    // scanned boxes in memory: the x order forward for the strategies that split by the segment's box, all six for the
-    // planes of EqualSize, none for PerSurface
-    const bool per_surface = B.strategy == RTX_SAH_PER_SURFACE, equal_size = B.strategy == RTX_SAH_EQUAL_SIZE;
-    B.L = per_surface ? nullptr : ar.take<double>((equal_size ? 18ull : 6ull) * n);
-    B.R = equal_size ? ar.take<double>(18ull * n) : nullptr;
     B.flags = ar.take<uint8_t>(n);
     B.before = ar.take<uint32_t>(n);
     B.F = ar.take<uint32_t>(n);
     B.G = ar.take<uint32_t>(n);
     B.ctl = ar.take<uint32_t>(CTL_WORDS);
     B.report = ar.take<uint32_t>(REPORT_WORDS);
-    B.seg_box = per_surface ? ar.take<double>(6ull * n) : nullptr;
     B.leaf_node = ar.take<uint32_t>(n);
+    p.sort_vals = ar.take<uint32_t>(n);
+    p.zeroed_bytes = ar.used;
+    // then coordinates, costs and boxes
+    B.box = ar.take<double>(6ull * n);
+    B.cen = ar.take<double>(3ull * n);
+    for (int c = 0; c < 2; ++c) {
+        for (int ax = 0; ax < 3; ++ax) B.skey[c][ax] = ar.take<double>(n);
+        B.best_cost[c] = ar.take<unsigned long long>((size_t)n + BEST_EXTRA);
+    }
+    B.seg_plane = ar.take<double>(n);
+    B.cand_cost = ar.take<unsigned long long>(3ull * B.n_pad);
+    // scanned boxes in memory: the x order forward for the strategies that split by the segment's box, all six for the
+    // planes of EqualSize, none for PerSurface
+    B.L = per_surface ? nullptr : ar.take<double>((equal_size ? 18ull : 6ull) * n);
+    B.R = equal_size ? ar.take<double>(18ull * n) : nullptr;
+    B.seg_box = per_surface ? ar.take<double>(6ull * n) : nullptr;
     B.node_right = ar.take<uint32_t>(B.n_nodes);
     B.node_prim = ar.take<uint32_t>(B.n_nodes);
     B.node_bmin = ar.take<double>(3ull * B.n_nodes);
     B.node_bmax = ar.take<double>(3ull * B.n_nodes);
     p.sort_keys_in = ar.take<unsigned long long>(3ull * n);
     p.sort_keys_out = ar.take<unsigned long long>(n);
-    p.sort_vals = ar.take<uint32_t>(n);
-    p.box_totals = ar.take<SBox>(6ull * ((n + SAH_TILE - 1u) / SAH_TILE > n_tiles ? (n + SAH_TILE - 1u) / SAH_TILE : n_tiles));
+    p.box_totals = ar.take<SBox>(6ull * (sah_tiles > n_tiles ? sah_tiles : n_tiles));
     p.count_totals = ar.take<SCount>(n_tiles);
     p.sort_tmp = ar.take<char>(sort_tmp_bytes);
     p.sort_tmp_bytes = sort_tmp_bytes;
@@ -1256,9 +1227,10 @@ int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_
     for (auto& e : ev) BUILD_TRY(hipEventCreate(&e));
     for (auto& e : level_done) BUILD_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     BUILD_TRY(hipEventRecord(ev[0], st));
-    // Every table starts as zeros: a level that the host enqueues after one that failed reads tables the failed level never
-    // wrote, and although its kernels look at the error word first, no index in them may ever come from stale memory.
-    BUILD_TRY(hipMemsetAsync(ar.base, 0, ar.size, st));
+    // The tables of positions and numbers start as zeros: a level that the host enqueues after one that failed finds tables
+    // the failed level never wrote, and although its kernels look at the error word first, nothing that could serve as an
+    // index may ever come from stale memory.
+    BUILD_TRY(hipMemsetAsync(ar.base, 0, plan.zeroed_bytes, st));
     BUILD_TRY(hipMemcpyAsync(const_cast<double*>(B.box), leaf_boxes, 6ull * n * sizeof(double), hipMemcpyHostToDevice, st));
 
     hipLaunchKernelGGL(k_init, dim3(grid), dim3(BLOCK), 0, st, B, plan.sort_keys_in, plan.sort_vals);
@@ -1287,15 +1259,10 @@ int build_bvh_device(const double* leaf_boxes, uint32_t n, int strategy, uint32_
         const uint32_t seg_grid = (seg_bound + BLOCK - 1u) / BLOCK;
         if (strategy == RTX_SAH_PER_SURFACE) {
             const uint32_t sah_tiles = (n + SAH_TILE - 1u) / SAH_TILE;
-            hipLaunchKernelGGL((k_sah_per_surface<false, false>), dim3(sah_tiles, 3), dim3(BLOCK), 0, st, B, cur, level, plan.box_totals);
-            if ((n >> (level < 31u ? level : 31u)) >= SAH_TILE) {   // segments of this level span tiles, on average
-                hipLaunchKernelGGL(k_box_spine, dim3(6), dim3(BLOCK), 0, st, sah_tiles, plan.box_totals);
-                hipLaunchKernelGGL(k_segment_areas, dim3(seg_grid), dim3(BLOCK), 0, st, B, cur, level, plan.box_totals, 1u);
-                hipLaunchKernelGGL((k_sah_per_surface<true, true>), dim3(sah_tiles, 3), dim3(BLOCK), 0, st, B, cur, level, plan.box_totals);
-            } else {
-                hipLaunchKernelGGL(k_segment_areas, dim3(seg_grid), dim3(BLOCK), 0, st, B, cur, level, plan.box_totals, 0u);
-                hipLaunchKernelGGL((k_sah_per_surface<true, false>), dim3(sah_tiles, 3), dim3(BLOCK), 0, st, B, cur, level, plan.box_totals);
-            }
+            hipLaunchKernelGGL(k_sah_per_surface<false>, dim3(sah_tiles, 3), dim3(BLOCK), 0, st, B, cur, level, plan.box_totals);
+            hipLaunchKernelGGL(k_box_spine, dim3(6), dim3(BLOCK), 0, st, sah_tiles, plan.box_totals);
+            hipLaunchKernelGGL(k_segment_areas, dim3(seg_grid), dim3(BLOCK), 0, st, B, cur, level, plan.box_totals);
+            hipLaunchKernelGGL(k_sah_per_surface<true>, dim3(sah_tiles, 3), dim3(BLOCK), 0, st, B, cur, level, plan.box_totals);
             hipLaunchKernelGGL(k_pick_per_surface, dim3(grid, 3), dim3(BLOCK), 0, st, B, cur, level);
         } else {
             // a midpoint split needs the segment boxes only (x order, forward); the planes of EqualSize need all six folds
