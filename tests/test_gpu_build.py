@@ -139,6 +139,23 @@ def test_random_soups(rt, kind, n, strategy, buckets):
     compare(rt, surfaces, strategy, buckets)
 
 
+@pytest.mark.parametrize("n", [5, 255, 511, 512, 513, 1023, 1537, 2050])
+def test_sizes_around_the_blocks_of_the_sah_passes(rt, n):
+    """The SAH passes scan 512 positions per block and the split 1024, four per thread: sizes that end just before,
+    on and just behind those edges (and are not multiples of four)."""
+    surfaces, _ = S.synthetic_soup(n=n, kind="spheres", seed=1000 + n)
+    compare(rt, surfaces, 3)
+    compare(rt, surfaces, 2, 16)
+
+
+@pytest.mark.parametrize("strategy,buckets", [(2, 16), (3, 0)], ids=["sah_equal_size_16", "sah_per_surface"])
+def test_runs_of_equal_keys_longer_than_a_block(rt, strategy, buckets):
+    """A lattice of 6000 spheres: on every axis hundreds to thousands of consecutive positions share a centroid
+    coordinate, so the positions that share a plane (and its cost) reach across several blocks of the pricing pass."""
+    compare(rt, lattice(40, 30, 5), strategy, buckets)
+    compare(rt, lattice(3, 2, 700), strategy, buckets)
+
+
 def test_large_soup_per_surface(rt):
     surfaces, _ = S.synthetic_soup(n=200_000, kind="spheres", seed=7)
     bvh = compare(rt, surfaces, 3)
