@@ -302,7 +302,7 @@ int rtx_render_multi(const rtx_scene_desc* desc, const rtx_camera* cam, uint64_t
  * op 3: out[i] = (float)a[i] / (float)b[i] in single precision. */
 int rtx_selftest_math(int op, const double* a, const double* b, uint64_t n, double* out);
 
-/* Philox4x32-10 uniform doubles of stream (seed, pixel, sample) computed on the device. */
+/* Philox4x32-7 uniform doubles of stream (seed, pixel, sample) computed on the device. */
 int rtx_selftest_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, double* out);
 
 #ifdef __cplusplus

@@ -84,8 +84,11 @@ _lib.orc_render.argtypes = [C.c_void_p, _p(ICamera), C.c_uint64, C.c_uint32, C.c
 _lib.orc_render.restype = None
 _lib.orc_ppm_quantize.argtypes = [_dp, C.c_uint64, _u8p]
 _lib.orc_ppm_quantize.restype = None
-_lib.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
-_lib.orc_philox4x32_10.restype = None
+_lib.orc_philox4x32.argtypes = [_u32p, _u32p, C.c_int, _u32p]
+_lib.orc_philox4x32.restype = None
+_lib.orc_philox_rounds.argtypes = []
+_lib.orc_philox_rounds.restype = C.c_int
+PHILOX_ROUNDS = _lib.orc_philox_rounds()
 _lib.orc_rng_stream.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _dp]
 _lib.orc_rng_stream.restype = None
 _lib.orc_scatter.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _dp]
@@ -225,9 +228,9 @@ def ppm_quantize(rgb):
     return out
 
 
-def philox4x32_10(ctr, key):
+def philox4x32(ctr, key, rounds=PHILOX_ROUNDS):
     c = np.asarray(ctr, np.uint32); k = np.asarray(key, np.uint32); o = np.zeros(4, np.uint32)
-    _lib.orc_philox4x32_10(_ptr(c, _u32p), _ptr(k, _u32p), _ptr(o, _u32p))
+    _lib.orc_philox4x32(_ptr(c, _u32p), _ptr(k, _u32p), int(rounds), _ptr(o, _u32p))
     return o
 
 

@@ -265,11 +265,13 @@ bool surface_from_desc(const orc_surface& s, uint32_t id, Surface& out) {
 }
 
 // ---------------------------------------------------------------- RNG
-// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3").
-inline void philox4x32_10(const uint32_t c_in[4], const uint32_t k_in[2], uint32_t out[4]) {
+// Philox4x32 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"); the path streams use seven rounds, the
+// fewest for which the paper reports the generator Crush-resistant.
+const int PHILOX_ROUNDS = 7;
+inline void philox4x32(const uint32_t c_in[4], const uint32_t k_in[2], int rounds, uint32_t out[4]) {
     uint32_t c0 = c_in[0], c1 = c_in[1], c2 = c_in[2], c3 = c_in[3];
     uint32_t k0 = k_in[0], k1 = k_in[1];
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -284,7 +286,7 @@ inline void philox4x32_10(const uint32_t c_in[4], const uint32_t k_in[2], uint32
 }
 
 // Random numbers of one path.  Stream = (seed, pixel index, sample index):
-// block b is Philox4x32-10 with counter (pixel, sample, b, 0) and key
+// block b is Philox4x32-7 with counter (pixel, sample, b, 0) and key
 // (seed_lo, seed_hi); it yields the 64-bit words w0 = out[1]:out[0] and
 // w1 = out[3]:out[2].
 //   * a uniform double takes one word, (w >> 11) * 2^-53 in [0,1), the same
@@ -308,7 +310,7 @@ struct PathRng {
     void begin_event() { draw = (draw + 1u) & ~1u; }
     void block(uint32_t blk, uint64_t& w0, uint64_t& w1) const {
         uint32_t c[4] = {pixel, sample, blk, 0u}, o[4];
-        philox4x32_10(c, key, o);
+        philox4x32(c, key, PHILOX_ROUNDS, o);
         w0 = ((uint64_t)o[1] << 32) | o[0];
         w1 = ((uint64_t)o[3] << 32) | o[2];
     }
@@ -1014,7 +1016,8 @@ void orc_ppm_quantize(const double* rgb, uint64_t n_pixels, uint8_t* out) {
     }
 }
 
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) { philox4x32(ctr, key, rounds, out); }
+int orc_philox_rounds(void) { return PHILOX_ROUNDS; }
 
 void orc_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, double* out) {
     PathRng rng(seed, pixel, sample);

@@ -143,8 +143,10 @@ void orc_render(const orc_scene*, const orc_icamera* cam, uint64_t seed,
 /* ppm_pixel (src/camera.rs:248-266) on n linear RGB triples -> n*3 bytes */
 void orc_ppm_quantize(const double* rgb, uint64_t n_pixels, uint8_t* out);
 
-/* Philox4x32-10 block (the seeded counter RNG that replaces rand's ThreadRng) */
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* Philox4x32 block with the given number of rounds; the path streams (the seeded counter RNG that replaces rand's
+ * ThreadRng) use orc_philox_rounds() of them */
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]);
+int orc_philox_rounds(void);
 /* first n uniform doubles of the stream (seed, pixel, sample) */
 void orc_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, double* out);
 

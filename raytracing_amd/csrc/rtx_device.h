@@ -230,13 +230,15 @@ __device__ __forceinline__ V3 refract(V3 r_in, V3 n, double eta) {              
 __device__ __forceinline__ V3 ld3(const double* p) { return v3(p[0], p[1], p[2]); }
 
 // ---------------------------------------------------------------- RNG
-// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3").
-// The 32x32->64 products are written as one 64-bit multiply each so that a
-// single v_mad_u64_u32 yields both halves.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+// Philox4x32 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3") with seven rounds: the fewest for which
+// the paper reports the generator Crush-resistant (its default of ten adds a safety margin; the multiplies of the
+// rounds are a sixth of this renderer's vector-ALU time).  The 32x32->64 products are written as one 64-bit multiply
+// each so that a single v_mad_u64_u32 yields both halves.
+constexpr int PHILOX_ROUNDS = 7;
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         // a ^ b ^ c in one instruction (v_bitop3_b32, truth table 0x96); the compiler emits two v_xor_b32 otherwise
@@ -250,7 +252,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 // Random numbers of one path.  Stream = (seed, pixel index, sample index):
-// block b is Philox4x32-10 with counter (pixel, sample, b, 0) and the 64-bit
+// block b is Philox4x32-7 with counter (pixel, sample, b, 0) and the 64-bit
 // seed as key; it yields the 64-bit words w0 = out[1]:out[0], w1 = out[3]:out[2].
 //   * a uniform double takes one word: (w >> 11) * 2^-53 (draw i is word
 //     i & 1 of block i >> 1);
@@ -272,7 +274,7 @@ struct PathRng {
         uint32_t blk = draw >> 1;
         if (blk != cached_block) {
             uint32_t o[4];
-            philox4x32_10(pixel, sample, blk, 0u, k0, k1, o);
+            philox4x32(pixel, sample, blk, 0u, k0, k1, o);
             uint64_t w0 = ((uint64_t)o[1] << 32) | o[0];
             uint64_t w1 = ((uint64_t)o[3] << 32) | o[2];
             cached[0] = (double)(w0 >> 11) * 0x1.0p-53;
@@ -288,7 +290,7 @@ struct PathRng {
     __device__ __forceinline__ void next3(double& a, double& b, double& c) {
         begin_event();
         uint32_t o[4];
-        philox4x32_10(pixel, sample, draw >> 1, 0u, k0, k1, o);
+        philox4x32(pixel, sample, draw >> 1, 0u, k0, k1, o);
         draw += 2u;
         const uint64_t w0 = ((uint64_t)o[1] << 32) | o[0];
         const uint64_t w1 = ((uint64_t)o[3] << 32) | o[2];
@@ -312,7 +314,7 @@ __device__ __forceinline__ V3 random_unit(PathRng& rng) {
 // boundary), for callers that keep no PathRng: candidate of one trial, and the first uniform of a block.
 __device__ __forceinline__ V3 random_unit_candidate(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk) {
     uint32_t o[4];
-    philox4x32_10(pixel, sample, blk, 0u, k0, k1, o);
+    philox4x32(pixel, sample, blk, 0u, k0, k1, o);
     const uint64_t w0 = ((uint64_t)o[1] << 32) | o[0];
     const uint64_t w1 = ((uint64_t)o[3] << 32) | o[2];
     // u = m * 2^-42 for a 42-bit integer m, then random_range(-1.0..1.0) = u * 2.0 + -1.0.  Both steps are exact, so
@@ -326,14 +328,14 @@ __device__ __forceinline__ V3 random_unit_candidate(uint32_t k0, uint32_t k1, ui
 }
 __device__ __forceinline__ double first_uniform_of_block(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk) {
     uint32_t o[4];
-    philox4x32_10(pixel, sample, blk, 0u, k0, k1, o);
+    philox4x32(pixel, sample, blk, 0u, k0, k1, o);
     const uint64_t w0 = ((uint64_t)o[1] << 32) | o[0];
     return (double)(w0 >> 11) * 0x1.0p-53;
 }
 // Both uniforms of block `blk` of a stream (draws 2*blk and 2*blk + 1)
 __device__ __forceinline__ void uniforms_of_block(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk, double& u0, double& u1) {
     uint32_t o[4];
-    philox4x32_10(pixel, sample, blk, 0u, k0, k1, o);
+    philox4x32(pixel, sample, blk, 0u, k0, k1, o);
     const uint64_t w0 = ((uint64_t)o[1] << 32) | o[0];
     const uint64_t w1 = ((uint64_t)o[3] << 32) | o[2];
     u0 = (double)(w0 >> 11) * 0x1.0p-53;

@@ -13,18 +13,28 @@ INF = float("inf")
 
 # ------------------------------------------------------------------ RNG
 def test_philox_known_answers(oracle):
-    # Random123 kat_vectors for philox4x32-10
-    assert [hex(x) for x in oracle.philox4x32_10([0] * 4, [0] * 2)] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
-    assert [hex(x) for x in oracle.philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2)] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
-    got = oracle.philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0])
-    assert [hex(x) for x in got] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+    """Random123's kat_vectors for philox4x32 with ten rounds (the generator's default) and with seven (what the path
+    streams use): the zero, all-ones and pi-digit counters and keys."""
+    zero, ones = ([0] * 4, [0] * 2), ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2)
+    pi = ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0])
+
+    def block(ck, rounds):
+        return [hex(x) for x in oracle.philox4x32(ck[0], ck[1], rounds)]
+
+    assert block(zero, 10) == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert block(ones, 10) == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    assert block(pi, 10) == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+    assert block(zero, 7) == ["0x5f6fb709", "0xd893f64", "0x4f121f81", "0x4f730a48"]
+    assert block(ones, 7) == ["0x5207ddc2", "0x45165e59", "0x4d8ee751", "0x8c52f662"]
+    assert block(pi, 7) == ["0x4dfccaba", "0x190a87f0", "0xc47362ba", "0xb6b5242a"]
+    assert oracle.PHILOX_ROUNDS == 7
 
 
 def test_rng_stream_mapping(oracle):
     seed, pixel, sample = 0x0123456789ABCDEF, 77, 5
     u = oracle.rng_stream(seed, pixel, sample, 6)
     for blk in range(3):
-        o = [int(x) for x in oracle.philox4x32_10([pixel, sample, blk, 0], [seed & 0xFFFFFFFF, seed >> 32])]
+        o = [int(x) for x in oracle.philox4x32([pixel, sample, blk, 0], [seed & 0xFFFFFFFF, seed >> 32])]
         w0, w1 = (o[1] << 32) | o[0], (o[3] << 32) | o[2]
         assert u[2 * blk] == (w0 >> 11) * 2.0 ** -53
         assert u[2 * blk + 1] == (w1 >> 11) * 2.0 ** -53
