@@ -111,14 +111,6 @@ __device__ __forceinline__ SBox shfl_up_t(const SBox& x, uint32_t d) {
     return r;
 }
 
-__device__ __forceinline__ SBox shfl_down_t(const SBox& x, uint32_t d) {
-    SBox r;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) r.v[k] = __shfl_down(x.v[k], d);
-    r.f = __shfl_down(x.f, d);
-    return r;
-}
-
 // AABB::merge (src/aabb.rs:40-53) folded along a list, starting again wherever a segment starts
 struct BoxOp {
     using T = SBox;
@@ -222,9 +214,9 @@ struct SegPlan {
 };
 
 // Inclusive segmented scan of BLOCK*N boxes held N per thread as coordinates x[i][0..5]; REV: from the block's last box to its
-// first.  starts: bit i = a segment starts at item i (REV: ends there).  carry (may be null: nothing) = what lies before
-// the block, carry_closed = it holds a segment start.  On return x holds the scan; if total is given, thread 0 stores the
-// fold of carry and block there.  lds_v / lds_f: scan::WAVES entries each.  Two barriers.
+// first.  starts: bit i = a segment starts at item i (REV: ends there).  carry (may be null: nothing) = the box of what
+// lies before the block.  On return x holds the scan; if total is given, thread 0 stores the fold of carry and block
+// there, flagged if a segment starts in the block.  lds_v / lds_f: scan::WAVES entries each.  Three barriers.
 template <bool REV, uint32_t N>
 __device__ __forceinline__ void block_scan_boxes(double (&x)[N][6], uint32_t starts, const double* carry, SBox* total, double (*lds_v)[6], uint32_t* lds_f) {
     // what of the thread's own items lies before item i in scan order, and whether item i is open to what comes before the thread
@@ -770,7 +762,7 @@ __device__ __forceinline__ uint32_t longest_axis(const double* bb) {
 
 // One thread per segment: fixes the split, writes the internal node and
 // opens the children (build_tree_rec, src/bvh/mod.rs:92-131).  The number of segments of a level lives on the device
-// (ctl[level & 3]); the host launches enough threads for the most a level can hold.
+// (ctl[ctl_count(level)]); the host launches enough threads for the most a level can hold.
 __global__ void __launch_bounds__(BLOCK) k_decide(DBuild B, uint32_t cur, uint32_t level) {
     const uint32_t s = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t n_seg = B.ctl[ctl_count(level)];
@@ -869,7 +861,8 @@ __device__ __forceinline__ bool passes(const DBuild& B, uint32_t axis, double at
 
 // Splits the three sorted orders stably and lists the pairs that partition_in_place swaps in the surface order.  Where
 // an element goes follows from the number of passing elements of its segment before it: a segmented count over the four
-// lists, scanned in two passes like the boxes above (APPLY = false: predicates and tile totals; true: counts and moves).
+// lists in two launches (APPLY = false: predicates and tile totals; true: what the tiles before carry in, folded back to
+// the nearest segment start, then counts and moves).
 template <bool APPLY>
 __global__ void __launch_bounds__(BLOCK) k_split(DBuild B, uint32_t cur, uint32_t level, SCount* totals) {
     __shared__ SCount lds[scan::WAVES];
