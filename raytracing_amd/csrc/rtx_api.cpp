@@ -671,6 +671,12 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
             if (pr[7])
                 std::fprintf(stderr, "PHASES per wave (cycles): generate %.0f traverse %.0f shade %.0f, life %.0f (longest %llu), %llu waves\n",
                              (double)pr[0] / pr[7], (double)pr[1] / pr[7], (double)pr[2] / pr[7], (double)pr[6] / pr[7], pr[9], pr[7]);
+            unsigned long long tr[14];
+            (void)hipMemcpy(tr, reinterpret_cast<unsigned long long*>(pp->ctl.p + 1), sizeof(tr), hipMemcpyDeviceToHost);
+            const double all = (double)(tr[0] + tr[1] + tr[2] + tr[3]);
+            if (all > 0)
+                std::fprintf(stderr, "PHASES of the walk (share of its cycles): refill %.3f node loop %.3f surface tests %.3f retire %.3f; %.1f node-loop steps per pass of the outer loop\n",
+                             tr[0] / all, tr[1] / all, tr[2] / all, tr[3] / all, tr[5] ? (double)tr[4] / tr[5] : 0.0);
         }
 #endif
         return RTX_OK;
