@@ -156,6 +156,30 @@ def committed_traffic(name):
         return None, None, None
 
 
+def committed_valu_issue(name):
+    """How busy the vector ALUs were on the headline frame, from the counter passes committed under profiles/ (not measured
+    in this run): vector instructions by kind x their issue cost (profiles/r01_valu_rate.txt: f64 and 64-bit integer
+    arithmetic 4 cycles of a SIMD per wave instruction, f32 and 32-bit integer 2.2, f64 division / square root steps 16) over
+    SIMDs x kernel cycles, and the share of lanes active in them.  The f64-flop fraction cannot say this: most vector
+    instructions of the path are not f64 arithmetic (f32 box tests, the generator's integer rounds, selects, addresses)."""
+    if name != "cover_spheres":
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) as fh:
+            ks = json.load(fh)["kernels"]
+        r = ks[next(k for k in ks if k.startswith(KERNEL + "<false"))]
+        simd_cycles = 1024.0 * r["GRBM_GUI_ACTIVE"] / 8.0   # the counter is summed over the eight XCDs
+        f64 = r["SQ_INSTS_VALU_ADD_F64"] + r["SQ_INSTS_VALU_FMA_F64"] + r["SQ_INSTS_VALU_MUL_F64"]
+        slow = f64 + r["SQ_INSTS_VALU_INT64"] + r["SQ_INSTS_VALU_CVT"]
+        fast = r["SQ_INSTS_VALU"] - slow - r["SQ_INSTS_VALU_TRANS_F64"]
+        return {"frac": round((4.0 * slow + 16.0 * r["SQ_INSTS_VALU_TRANS_F64"] + 2.2 * fast) / simd_cycles, 3),
+                "frac_if_every_instruction_took_4_cycles": round(4.0 * r["SQ_INSTS_VALU"] / simd_cycles, 3),
+                "lanes_active": round(r["SQ_THREAD_CYCLES_VALU"] / (r["SQ_ACTIVE_INST_VALU"] * 64.0), 3),
+                "source": "profiles/r02_pmc_summary.json (committed, not of this run), issue costs from profiles/r01_valu_rate.txt"}
+    except (OSError, KeyError, ValueError, StopIteration, ZeroDivisionError):
+        return None
+
+
 def live_traffic(args):
     """HBM bytes of one launch of the render kernel on THIS box: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do
     not fit in one) over a child run of this script that renders one frame.  FETCH_SIZE counts a 128-byte request as 64 bytes
@@ -455,6 +479,7 @@ def roofline(rt, scene, n_nodes, icam, stats, begin, count, acc, stream, args):
         "rounds_of_busiest_wave": int(max(s.iterations for s in stats)),
         "hbm": hbm,
         "valu_f64": {"achieved_tflops": round(tf, 3), "peak_tflops": FP64_VECTOR_PEAK_TF, "frac": round(tf / FP64_VECTOR_PEAK_TF, 4)},
+        "valu_issue": committed_valu_issue(args.config),
         "on_chip_note": f"{scene_bytes_per_ray:.0f} B/ray of the byte formula are node and surface records "
                         + ("served from LDS (the tree and the surface tables are copied there once per block): not HBM traffic"
                            if tree_on_chip else "read from global memory (the tree is far larger than LDS and L2)"),
