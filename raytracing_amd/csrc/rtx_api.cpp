@@ -435,7 +435,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     sc->d.n_planars = (uint32_t)planars.size();
     sc->d.rec_user_id = sc->rec_user_id.p;
     sc->d.shade_recs = sc->shade_recs.p;
-    sc->f32_ok = f32_ok && filter_ok;
+    sc->f32_ok = f32_ok && filter_ok && n < (1u << 25);   // the f32 walk keeps two flags above a record's byte offset (n * 32 < 2^30)
     if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
         return bail(fail(RTX_ERR_HIP, "hipEventCreate failed"));
     // Set-up of the allocation-free closest-hit entry: where this device keeps its copy of the scratch array.

@@ -621,33 +621,39 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
         ++pt_outer;
 #endif
         // ---- phase 1: walk to the next leaf whose box is hit
-        // (a lane that found its leaf waits; so does a lane whose box test the f32 tier could not decide, at
-        // that node; the loop also ends as soon as PEND_AT lanes are waiting, so a few long searches do not stall them)
+        // A lane that found its leaf waits; so does a lane whose box test the f32 tier could not decide, at that node (the
+        // exact tiers run after the loop, for all such lanes together).  The loop also ends as soon as PEND_AT lanes are
+        // waiting, so a few long searches do not stall them.  The lane's state is one register: `at` is the record it stands
+        // on; it is `end` or beyond once the lane has nothing to walk (idle, out of tree), and carries WAIT or OPEN in its
+        // top bits while the lane waits on a leaf or on an undecided box.  With the state in flags the loop spent as many
+        // scalar instructions on who walks, waits or is done as vector instructions on the box test, and the scalar chain
+        // is what a step waits for.
+        constexpr uint32_t WAIT = 0x80000000u, OPEN = 0x40000000u;   // (records lie below 2^30: checked when the scene is created)
         uint32_t n_pending = 0;   // wave-uniform
-        bool searching = idx != NONE && node < end;
         bool undecided = false;
-        while (searching) {       // lanes leave the loop one by one; the wave stays until all have left
+        uint32_t at = idx != NONE ? node : end;
+        while (at < end) {        // lanes leave the loop one by one; the wave stays until all have left
             // the record: six planes (f32, or grid steps as f32), whether it is a leaf, its surface code if so,
             // and the byte offset of the record that follows its subtree
             float planes[6];
             bool is_leaf, contained = false;
             uint32_t leaf_code, succ;
             if (REC16) {
-                const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes16) + node);
+                const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes16) + at);
                 planes[0] = (float)(r.x & 0xFFFFu); planes[1] = (float)(r.x >> 16);
                 planes[2] = (float)(r.y & 0xFFFFu); planes[3] = (float)(r.y >> 16);
                 planes[4] = (float)(r.z & 0xFFFFu); planes[5] = (float)(r.z >> 16);
                 is_leaf = r.w < NODE16_INTERNAL;
                 leaf_code = r.w;
-                succ = is_leaf ? node + 16u : r.w << 4;   // the tag bits shift out; a leaf is followed by the next record
+                succ = is_leaf ? at + 16u : r.w << 4;   // the tag bits shift out; a leaf is followed by the next record
             } else {
                 uint4 n0, n1;
                 if (LDS_NODES) {
-                    const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + node);
+                    const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + at);
                     n0 = np[0];
                     n1 = np[1];
                 } else {
-                    const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + node);
+                    const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + at);
                     n0 = np[0];
                     n1 = np[1];
                 }
@@ -672,28 +678,23 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
             }
             // The lanes that start waiting in this step are counted from the comparisons' own masks (the ballot of a
             // combined flag costs two vector instructions per step): f32 says hit (that implies decided) on a leaf ...
-            uint32_t n_new = (uint32_t)__popcll(ballot64(hit) & ballot64(is_leaf));
-            if (batch_undecided) n_new += (uint32_t)__popcll(ballot64(true) & ~ballot64(decided));   // ... or undecided
-            if (!decided && !batch_undecided) {   // few such tests in this scene: the exact box, f64 filter, then the division form, here
-                const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> REC_SHIFT));
-                const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
-                if (COUNT) ++c_fallback;
-                hit = tier2_box(q0, q1, q2, o, d, tmin, tmax, scene_filter);
-                decided = true;   // (a leaf found here waits uncounted: counting inside this branch would make the count per-lane)
-            }
-            const bool found = decided && hit && is_leaf;
-            if (decided) node = (hit && !is_leaf) ? node + REC_BYTES : succ;   // links are byte offsets; a leaf's successor is its miss link as well
+            n_pending += (uint32_t)__popcll(ballot64(hit) & ballot64(is_leaf));
+            if (batch_undecided) n_pending += (uint32_t)__popcll(ballot64(true) & ~ballot64(decided));   // ... or, where there are many, undecided
             leaf = leaf_code;   // only read once the lane waits on this leaf; a lane that walks on overwrites it
-            pending = found;
-            undecided = !decided;
-            n_pending += n_new;
-            searching = decided && !found && node < end;
+            const uint32_t down = is_leaf ? (succ | WAIT) : at + REC_BYTES;   // links are byte offsets; a leaf's successor is its miss link as well
+            const uint32_t next = hit ? down : succ;
+            at = decided ? next : (at | OPEN);
 #ifdef RTX_PROFILE_PHASES
             ++pt_iters;
 #endif
             if (n_pending >= PEND_AT) break;   // wave-uniform
         }
-        // ---- phase 1b (scenes with many such tests): the boxes left undecided, for all waiting lanes together
+        if (idx != NONE) {
+            pending = (at & WAIT) != 0u;
+            undecided = (at & OPEN) != 0u;
+            node = at & ~(WAIT | OPEN);
+        }
+        // ---- phase 1b: the boxes left undecided, for all such lanes together
         if (undecided) {
 #ifdef RTX_PROFILE_PHASES
             ++pt_fb_iters;
