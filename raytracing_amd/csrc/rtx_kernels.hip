@@ -54,6 +54,9 @@ __device__ __forceinline__ uint32_t uniform32(uint32_t v) { return (uint32_t)__b
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
     return ((unsigned long long)uniform32((uint32_t)(v >> 32)) << 32) | (unsigned long long)uniform32((uint32_t)v);
 }
+__device__ __forceinline__ double uniform_f64(double v) {
+    return __longlong_as_double((long long)uniform64((unsigned long long)__double_as_longlong(v)));
+}
 __device__ __forceinline__ uint32_t rank_below(unsigned long long mask, uint32_t lane) {
     return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
@@ -877,6 +880,173 @@ __device__ __noinline__ double2 sphere_uv(double px, double py, double pz) {
     return make_double2(phi / (2.0 * PI), theta / PI);
 }
 
+// ---- memory operations of the shade phase in the kernel form that reads a whole row ahead (shade_wave<true>)
+// A wave's memory operations complete in the order they were issued, and `s_waitcnt vmcnt(N)` waits until at most N are
+// outstanding.  A row's loads are issued one row ahead; between them and their first use lie the previous row's atomics and
+// stores.  Written in C++ those sit in conditional blocks, the compiler must assume them skipped, waits for `vmcnt(0)` and with
+// that for the round trip of stores issued a moment ago, once per row.  Here every row issues exactly ROW_TAIL_OPS operations
+// after its loads (lanes that have nothing to add or store are masked out, the instruction is still issued and counted), so the
+// wait for the row's loads is `vmcnt(ROW_TAIL_OPS)` and leaves the stores in flight.  The compiler does not know of these loads:
+// their results may only be used after row_wait().
+constexpr int ROW_TAIL_OPS = 16;   // 3 atomics + 13 stores
+struct RowAhead {
+    uint32_t handle, pixel, sample, draw, depth;
+    double t;
+    V3 o, d, beta;
+};
+// issues the 15 loads of ray `i`'s state and hit record, for the lanes of `mask`
+__device__ __forceinline__ void row_request(RowAhead& r, unsigned long long mask, uint32_t i, const DState& cur, const DHits& hits) {
+    unsigned long long addr, saved;
+    const unsigned long long i64 = i;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[mk]\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 2, %[p0]\n\t"
+        "global_load_dword %[a0], %[ad], off nt\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 2, %[p1]\n\t"
+        "global_load_dword %[a1], %[ad], off nt\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 2, %[p2]\n\t"
+        "global_load_dword %[a2], %[ad], off nt\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 2, %[p3]\n\t"
+        "global_load_dword %[a3], %[ad], off nt\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 2, %[p4]\n\t"
+        "global_load_dword %[a4], %[ad], off nt\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [a0] "+v"(r.handle), [a1] "+v"(r.pixel), [a2] "+v"(r.sample), [a3] "+v"(r.draw), [a4] "+v"(r.depth), [ad] "=&v"(addr), [sv] "=&s"(saved)
+        : [mk] "s"(mask), [i] "v"(i64), [p0] "s"(hits.prim), [p1] "s"(cur.pixel), [p2] "s"(cur.sample), [p3] "s"(cur.draw), [p4] "s"(cur.depth)
+        : "memory");
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[mk]\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 3, %[p0]\n\t"
+        "global_load_dwordx2 %[a0], %[ad], off nt\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 3, %[p1]\n\t"
+        "global_load_dwordx2 %[a1], %[ad], off nt\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 3, %[p2]\n\t"
+        "global_load_dwordx2 %[a2], %[ad], off nt\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 3, %[p3]\n\t"
+        "global_load_dwordx2 %[a3], %[ad], off nt\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [a0] "+v"(r.t), [a1] "+v"(r.o.x), [a2] "+v"(r.o.y), [a3] "+v"(r.o.z), [ad] "=&v"(addr), [sv] "=&s"(saved)
+        : [mk] "s"(mask), [i] "v"(i64), [p0] "s"(hits.t), [p1] "s"(cur.ox), [p2] "s"(cur.oy), [p3] "s"(cur.oz)
+        : "memory");
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[mk]\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 3, %[p0]\n\t"
+        "global_load_dwordx2 %[a0], %[ad], off nt\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 3, %[p1]\n\t"
+        "global_load_dwordx2 %[a1], %[ad], off nt\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 3, %[p2]\n\t"
+        "global_load_dwordx2 %[a2], %[ad], off nt\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 3, %[p3]\n\t"
+        "global_load_dwordx2 %[a3], %[ad], off nt\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 3, %[p4]\n\t"
+        "global_load_dwordx2 %[a4], %[ad], off nt\n\t"
+        "v_lshl_add_u64 %[ad], %[i], 3, %[p5]\n\t"
+        "global_load_dwordx2 %[a5], %[ad], off nt\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [a0] "+v"(r.d.x), [a1] "+v"(r.d.y), [a2] "+v"(r.d.z), [a3] "+v"(r.beta.x), [a4] "+v"(r.beta.y), [a5] "+v"(r.beta.z), [ad] "=&v"(addr),
+          [sv] "=&s"(saved)
+        : [mk] "s"(mask), [i] "v"(i64), [p0] "s"(cur.dx), [p1] "s"(cur.dy), [p2] "s"(cur.dz), [p3] "s"(cur.bx), [p4] "s"(cur.by), [p5] "s"(cur.bz)
+        : "memory");
+}
+// Waits for the loads of row_request() and hands the row over in registers of its own, so that `ahead` can be requested again at
+// once.  The copies are part of the statement that waits: a copy the compiler made by itself could be scheduled before the wait,
+// while the registers are still being written.  TAIL: a row_tail() has been issued since the request, and may stay in flight.
+template <bool TAIL>
+__device__ __forceinline__ RowAhead row_wait(const RowAhead& ahead) {
+    static_assert(ROW_TAIL_OPS == 16, "the waits below name the number of operations of row_tail()");
+    RowAhead r;
+#define RTX_ROW_WAIT_A(WAIT)                                                                                                            \
+    asm volatile(WAIT "\n\tv_mov_b32 %0, %9\n\tv_mov_b32 %1, %10\n\tv_mov_b32 %2, %11\n\tv_mov_b32 %3, %12\n\tv_mov_b32 %4, %13\n\t" \
+                      "v_mov_b64 %5, %14\n\tv_mov_b64 %6, %15\n\tv_mov_b64 %7, %16\n\tv_mov_b64 %8, %17"                             \
+                 : "=&v"(r.handle), "=&v"(r.pixel), "=&v"(r.sample), "=&v"(r.draw), "=&v"(r.depth), "=&v"(r.t), "=&v"(r.o.x), "=&v"(r.o.y),     \
+                   "=&v"(r.o.z)                                                                                                         \
+                 : "v"(ahead.handle), "v"(ahead.pixel), "v"(ahead.sample), "v"(ahead.draw), "v"(ahead.depth), "v"(ahead.t), "v"(ahead.o.x), \
+                   "v"(ahead.o.y), "v"(ahead.o.z)                                                                                       \
+                 : "memory")
+#define RTX_ROW_WAIT_B(WAIT)                                                                                                            \
+    asm volatile(WAIT "\n\tv_mov_b64 %0, %6\n\tv_mov_b64 %1, %7\n\tv_mov_b64 %2, %8\n\tv_mov_b64 %3, %9\n\tv_mov_b64 %4, %10\n\t"      \
+                      "v_mov_b64 %5, %11"                                                                                               \
+                 : "=&v"(r.d.x), "=&v"(r.d.y), "=&v"(r.d.z), "=&v"(r.beta.x), "=&v"(r.beta.y), "=&v"(r.beta.z)                              \
+                 : "v"(ahead.d.x), "v"(ahead.d.y), "v"(ahead.d.z), "v"(ahead.beta.x), "v"(ahead.beta.y), "v"(ahead.beta.z)                  \
+                 : "memory")
+    if (TAIL) {
+        RTX_ROW_WAIT_A("s_waitcnt vmcnt(16)");
+        RTX_ROW_WAIT_B("s_waitcnt vmcnt(16)");
+    } else {
+        RTX_ROW_WAIT_A("s_waitcnt vmcnt(0)");
+        RTX_ROW_WAIT_B("s_waitcnt vmcnt(0)");
+    }
+#undef RTX_ROW_WAIT_A
+#undef RTX_ROW_WAIT_B
+    return r;
+}
+// A row's atomics (radiance of the finished paths into the pixel at `px`, one mask per component) and the 13 stores of the
+// surviving rays' state to slot `k` (lanes of `alive`): always ROW_TAIL_OPS operations.
+__device__ __forceinline__ void row_tail(unsigned long long add_x, unsigned long long add_y, unsigned long long add_z, double* px, V3 radiance,
+                                         unsigned long long alive, uint32_t k, const DState& nxt, V3 p, V3 nd, V3 beta, uint32_t pixel,
+                                         uint32_t sample, uint32_t draw, uint32_t depth) {
+    unsigned long long addr, saved;
+    const unsigned long long k64 = k;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[mx]\n\t"
+        "global_atomic_add_f64 %[px], %[rx], off\n\t"
+        "s_mov_b64 exec, %[my]\n\t"
+        "global_atomic_add_f64 %[px], %[ry], off offset:8\n\t"
+        "s_mov_b64 exec, %[mz]\n\t"
+        "global_atomic_add_f64 %[px], %[rz], off offset:16\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [sv] "=&s"(saved)
+        : [mx] "s"(add_x), [my] "s"(add_y), [mz] "s"(add_z), [px] "v"(px), [rx] "v"(radiance.x), [ry] "v"(radiance.y), [rz] "v"(radiance.z)
+        : "memory");
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[mk]\n\t"
+        "v_lshl_add_u64 %[ad], %[k], 3, %[p0]\n\t"
+        "global_store_dwordx2 %[ad], %[a0], off\n\t"
+        "v_lshl_add_u64 %[ad], %[k], 3, %[p1]\n\t"
+        "global_store_dwordx2 %[ad], %[a1], off\n\t"
+        "v_lshl_add_u64 %[ad], %[k], 3, %[p2]\n\t"
+        "global_store_dwordx2 %[ad], %[a2], off\n\t"
+        "v_lshl_add_u64 %[ad], %[k], 3, %[p3]\n\t"
+        "global_store_dwordx2 %[ad], %[a3], off\n\t"
+        "v_lshl_add_u64 %[ad], %[k], 3, %[p4]\n\t"
+        "global_store_dwordx2 %[ad], %[a4], off\n\t"
+        "v_lshl_add_u64 %[ad], %[k], 3, %[p5]\n\t"
+        "global_store_dwordx2 %[ad], %[a5], off\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [ad] "=&v"(addr), [sv] "=&s"(saved)
+        : [mk] "s"(alive), [k] "v"(k64), [p0] "s"(nxt.ox), [p1] "s"(nxt.oy), [p2] "s"(nxt.oz), [p3] "s"(nxt.dx), [p4] "s"(nxt.dy), [p5] "s"(nxt.dz),
+          [a0] "v"(p.x), [a1] "v"(p.y), [a2] "v"(p.z), [a3] "v"(nd.x), [a4] "v"(nd.y), [a5] "v"(nd.z)
+        : "memory");
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[mk]\n\t"
+        "v_lshl_add_u64 %[ad], %[k], 3, %[p0]\n\t"
+        "global_store_dwordx2 %[ad], %[a0], off\n\t"
+        "v_lshl_add_u64 %[ad], %[k], 3, %[p1]\n\t"
+        "global_store_dwordx2 %[ad], %[a1], off\n\t"
+        "v_lshl_add_u64 %[ad], %[k], 3, %[p2]\n\t"
+        "global_store_dwordx2 %[ad], %[a2], off\n\t"
+        "v_lshl_add_u64 %[ad], %[k], 2, %[p3]\n\t"
+        "global_store_dword %[ad], %[a3], off\n\t"
+        "v_lshl_add_u64 %[ad], %[k], 2, %[p4]\n\t"
+        "global_store_dword %[ad], %[a4], off\n\t"
+        "v_lshl_add_u64 %[ad], %[k], 2, %[p5]\n\t"
+        "global_store_dword %[ad], %[a5], off\n\t"
+        "v_lshl_add_u64 %[ad], %[k], 2, %[p6]\n\t"
+        "global_store_dword %[ad], %[a6], off\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [ad] "=&v"(addr), [sv] "=&s"(saved)
+        : [mk] "s"(alive), [k] "v"(k64), [p0] "s"(nxt.bx), [p1] "s"(nxt.by), [p2] "s"(nxt.bz), [p3] "s"(nxt.pixel), [p4] "s"(nxt.sample),
+          [p5] "s"(nxt.draw), [p6] "s"(nxt.depth), [a0] "v"(beta.x), [a1] "v"(beta.y), [a2] "v"(beta.z), [a3] "v"(pixel), [a4] "v"(sample),
+          [a5] "v"(draw), [a6] "v"(depth)
+        : "memory");
+}
+
 // One step of ray_color (src/camera.rs:184-208) in its iterative form:
 //   miss            -> add beta * background, path ends
 //   hit             -> add beta * emitted; scatter ? (beta *= attenuation, new ray) : path ends
@@ -896,23 +1066,20 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
     // What the sampling at the top of a row needs (hit, pixel, sample, draw count) is read one row ahead, so a row starts
     // computing at once while the rest of its state and the record of its surface are on their way.
     uint32_t handle_n = NONE, pixel_n = 0, sample_n = 0, draw_n = 0;
-    // DEEP (the kernel form with registers to spare): the whole state of the next row is read one row ahead
-    uint32_t depth_n = 0;
-    double t_n = 0.0;
-    V3 o_n = v3(0, 0, 0), d_n = v3(0, 0, 0), beta_n = v3(0, 0, 0);
-    if (lane < count) {
+    // DEEP (the kernel form with registers to spare): the whole state of the next row is read one row ahead, by the row_* helpers
+    RowAhead ahead;
+    ahead.handle = NONE; ahead.pixel = 0; ahead.sample = 0; ahead.draw = 0; ahead.depth = 0; ahead.t = 0.0;
+    ahead.o = v3(0, 0, 0); ahead.d = v3(0, 0, 0); ahead.beta = v3(0, 0, 0);
+    // what every row reads of the camera, once (through the reference these were loads in every row)
+    const uint32_t max_depth = uniform32(cam.max_depth);
+    const V3 background = v3(uniform_f64(cam.background[0]), uniform_f64(cam.background[1]), uniform_f64(cam.background[2]));
+    if (DEEP) {
+        row_request(ahead, ballot64(lane < count), base + lane, cur, hits);
+    } else if (lane < count) {
         handle_n = ld_stream(&hits.prim[base + lane]);
         pixel_n = ld_stream(&cur.pixel[base + lane]);
         sample_n = ld_stream(&cur.sample[base + lane]);
         draw_n = ld_stream(&cur.draw[base + lane]);
-        if (DEEP) {
-            const uint32_t i = base + lane;
-            t_n = ld_stream(&hits.t[i]);
-            o_n = v3(ld_stream(&cur.ox[i]), ld_stream(&cur.oy[i]), ld_stream(&cur.oz[i]));
-            d_n = v3(ld_stream(&cur.dx[i]), ld_stream(&cur.dy[i]), ld_stream(&cur.dz[i]));
-            beta_n = v3(ld_stream(&cur.bx[i]), ld_stream(&cur.by[i]), ld_stream(&cur.bz[i]));
-            depth_n = ld_stream(&cur.depth[i]);
-        }
     }
     for (uint32_t t0 = 0; t0 < count; t0 += 64u) {
         const uint32_t off = t0 + lane;
@@ -920,31 +1087,30 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
         bool alive = false;
         V3 p = v3(0, 0, 0), nd = v3(0, 0, 0), beta = v3(0, 0, 0);
         uint32_t draw = 0, depth = 0;
-        const uint32_t handle = handle_n, pixel = pixel_n, sample = sample_n, draw0 = draw_n;
-        uint32_t depth0 = 0;
+        uint32_t handle, pixel, sample, draw0, depth0 = 0;
         double t = 0.0;
         V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
         if (DEEP) {
-            t = t_n; o = o_n; d = d_n; beta = beta_n; depth0 = depth_n;
-        } else if (off < count) {
-            t = ld_stream(&hits.t[i]);
-            o = v3(ld_stream(&cur.ox[i]), ld_stream(&cur.oy[i]), ld_stream(&cur.oz[i]));
-            d = v3(ld_stream(&cur.dx[i]), ld_stream(&cur.dy[i]), ld_stream(&cur.dz[i]));
-            beta = v3(ld_stream(&cur.bx[i]), ld_stream(&cur.by[i]), ld_stream(&cur.bz[i]));
-            depth0 = ld_stream(&cur.depth[i]);
-        }
-        handle_n = NONE;
-        if (off + 64u < count) {
-            handle_n = ld_stream(&hits.prim[i + 64u]);
-            pixel_n = ld_stream(&cur.pixel[i + 64u]);
-            sample_n = ld_stream(&cur.sample[i + 64u]);
-            draw_n = ld_stream(&cur.draw[i + 64u]);
-            if (DEEP) {
-                t_n = ld_stream(&hits.t[i + 64u]);
-                o_n = v3(ld_stream(&cur.ox[i + 64u]), ld_stream(&cur.oy[i + 64u]), ld_stream(&cur.oz[i + 64u]));
-                d_n = v3(ld_stream(&cur.dx[i + 64u]), ld_stream(&cur.dy[i + 64u]), ld_stream(&cur.dz[i + 64u]));
-                beta_n = v3(ld_stream(&cur.bx[i + 64u]), ld_stream(&cur.by[i + 64u]), ld_stream(&cur.bz[i + 64u]));
-                depth_n = ld_stream(&cur.depth[i + 64u]);
+            // (lanes beyond `count` carry what an earlier row left: everything below asks off < count first)
+            const RowAhead row = t0 == 0u ? row_wait<false>(ahead) : row_wait<true>(ahead);   // every row but the first follows a row_tail()
+            handle = row.handle; pixel = row.pixel; sample = row.sample; draw0 = row.draw; depth0 = row.depth;
+            t = row.t; o = row.o; d = row.d; beta = row.beta;
+            row_request(ahead, ballot64(off + 64u < count), i + 64u, cur, hits);
+        } else {
+            handle = handle_n; pixel = pixel_n; sample = sample_n; draw0 = draw_n;
+            if (off < count) {
+                t = ld_stream(&hits.t[i]);
+                o = v3(ld_stream(&cur.ox[i]), ld_stream(&cur.oy[i]), ld_stream(&cur.oz[i]));
+                d = v3(ld_stream(&cur.dx[i]), ld_stream(&cur.dy[i]), ld_stream(&cur.dz[i]));
+                beta = v3(ld_stream(&cur.bx[i]), ld_stream(&cur.by[i]), ld_stream(&cur.bz[i]));
+                depth0 = ld_stream(&cur.depth[i]);
+            }
+            handle_n = NONE;
+            if (off + 64u < count) {
+                handle_n = ld_stream(&hits.prim[i + 64u]);
+                pixel_n = ld_stream(&cur.pixel[i + 64u]);
+                sample_n = ld_stream(&cur.sample[i + 64u]);
+                draw_n = ld_stream(&cur.draw[i + 64u]);
             }
         }
         // the record of the surface that was hit: requested as soon as the hit is known, so that it arrives during the sampling below
@@ -967,11 +1133,11 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
         V3 ru_cand;
         uint32_t ru_trials;
         random_unit_wave(off < count && handle != NONE && code_mat(handle) <= 1u, k0, k1, pixel, sample, draw_ev >> 1, ru_cand, ru_trials);
+        V3 radiance = v3(0.0, 0.0, 0.0);
+        bool add = false;
         if (off < count) {
-            V3 radiance = v3(0.0, 0.0, 0.0);
-            bool add = false;
             if (handle == NONE) {
-                radiance = beta * ld3(cam.background);   // camera.rs:207
+                radiance = beta * background;   // camera.rs:207
                 add = true;
             } else {
                 const uint32_t mkind = code_mat(handle), slot = code_slot(handle);
@@ -1047,13 +1213,13 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
                     scattered = true;
                 }
                 depth = depth0 + 1u;
-                if (scattered && depth < cam.max_depth) {
+                if (scattered && depth < max_depth) {
                     beta = beta * att;
                     draw = draw_ev;
                     alive = true;
                 }
             }
-            if (add) {
+            if (!DEEP && add) {
                 double* px = accum + 3 * (size_t)pixel;
                 if (radiance.x != 0.0) unsafeAtomicAdd(px + 0, radiance.x);
                 if (radiance.y != 0.0) unsafeAtomicAdd(px + 1, radiance.y);
@@ -1062,7 +1228,10 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
         }
         // compaction: 64-wide ballot + prefix popcount; the wave is the only writer of its sub-pool
         const unsigned long long amask = ballot64(alive);
-        if (alive) {
+        if (DEEP) {
+            row_tail(ballot64(add && radiance.x != 0.0), ballot64(add && radiance.y != 0.0), ballot64(add && radiance.z != 0.0),
+                     accum + 3 * (size_t)pixel, radiance, amask, base + n_out + rank_below(amask, lane), nxt, p, nd, beta, pixel, sample, draw, depth);
+        } else if (alive) {
             const uint32_t k = base + n_out + rank_below(amask, lane);
             st_stream(&nxt.ox[k], p.x); st_stream(&nxt.oy[k], p.y); st_stream(&nxt.oz[k], p.z);
             st_stream(&nxt.dx[k], nd.x); st_stream(&nxt.dy[k], nd.y); st_stream(&nxt.dz[k], nd.z);
