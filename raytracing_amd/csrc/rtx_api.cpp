@@ -423,6 +423,10 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     // dominate (Cornell box +8 %, quads +4 %; the headline scene loses 2 % with 16, a 10^6-triangle tree in global memory 5 %).
     sc->d.refill_at = env_u32("RTX_REFILL_AT", planar_scene && small_scene ? 16u : 32u);
     if (sc->d.refill_at > 64u) sc->d.refill_at = 64u;
+    // The kernel that keeps the paths in registers runs a bounce (some 1500 instructions whatever the number of lanes in it) once this
+    // many lanes are due: 16 / 24 / 32 / 40 / 48 / 56 / 64 give 51.8 / 45.2 / 42.5 / 40.7 / 40.3 / 40.4 / 44.9 ms per 100 spp of the headline frame.
+    sc->d.bounce_at = env_u32("RTX_BOUNCE_AT", 48u);
+    if (sc->d.bounce_at > 64u) sc->d.bounce_at = 64u;
     sc->d.nodes32 = sc->nodes32.p;
     sc->d.nodes16 = q16_ok ? sc->nodes16.p : nullptr;
     for (int a = 0; a < 3; ++a) {
@@ -605,7 +609,13 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         }
         if (mode == 2u) lds_recs = persistent_lds_bytes(sc->d, 2u, true) <= env_u32("RTX_LDS_SCENE_BYTES", 32u * 1024u);
         if (env_u32("RTX_LDS_RECS", 1, true) == 0u) lds_recs = false;
-        const uint32_t waves = sc->n_cus * persistent_waves_per_cu(sc->d, mode, lds_recs);   // exactly what is resident at once
+        // Scenes that sit in LDS whole (tree, surface tables and shade records) take the resident form: paths stay in registers from
+        // bounce to bounce, the pool below holds nothing (RTX_RESIDENT=0 keeps the pooled form; the work counters exist there only).
+        const uint32_t resident_waves = (mode == 3u && lds_recs && !(flags & RTX_FLAG_COUNT_WORK) && env_u32("RTX_RESIDENT", 0, true) != 0u)
+                                            ? resident_waves_per_cu(sc->d)
+                                            : 0u;
+        const bool resident = resident_waves != 0u;
+        const uint32_t waves = sc->n_cus * (resident ? resident_waves : persistent_waves_per_cu(sc->d, mode, lds_recs));   // exactly what is resident at once
         const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 22);   // ~800 slots per wave: a round ends with a drain, so long rounds pay, but state that stays in the last-level cache pays too
         const uint64_t need = total < want ? total : want;
         uint32_t n_sub;
@@ -645,7 +655,8 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         HIP_TRY(hipMemcpyAsync(pp->params.p, &P, sizeof(P), hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(pp->ring_ev[slot], s));   // the slot may be refilled once both uploads have executed
         HIP_TRY(hipEventRecord(sc->ev0, s));
-        launch_render_persistent(pp->params.p, P, (flags & RTX_FLAG_COUNT_WORK) != 0, mode, s);
+        if (resident) launch_render_resident(pp->params.p, P, s);
+        else launch_render_persistent(pp->params.p, P, (flags & RTX_FLAG_COUNT_WORK) != 0, mode, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(sc->ev1, s));
         if (no_wait) return RTX_OK;

@@ -110,6 +110,7 @@ struct DScene {
     uint32_t batch_undecided;   // box tests the f32 tier leaves open are resolved for many lanes at once, after the node walk
     uint32_t pend_at;           // the walk runs the waiting lanes' surface tests once this many lanes wait
     uint32_t refill_at;         // ... and gives idle lanes their next rays once this many lanes are idle
+    uint32_t bounce_at;         // kernel with the paths in registers: one bounce once this many lanes have finished their walk or hold no path
     const DNode32* nodes32;
     const DBox64* boxes64;
     uint32_t n_spheres, n_planars;

@@ -551,7 +551,172 @@ struct WorkCounters {
     unsigned long long nodes = 0, spheres = 0, planars = 0, fallbacks = 0;
 };
 
+// Counters of an instrumented build (-DRTX_PROFILE_PHASES): where a wave's cycles go in the closest-hit walk
+#ifdef RTX_PROFILE_PHASES
+struct WalkProfile {
+    long long fb_iters = 0, fb_cycles = 0, refill = 0, p1 = 0, p2 = 0, retire = 0, iters = 0, outer = 0, mark = 0;
+};
+#define PT(field) do { const long long now_ = clock64(); prof.field += now_ - prof.mark; prof.mark = now_; } while (0)
+#else
+struct WalkProfile {};
+#define PT(field) do {} while (0)
+#endif
+
+// One pass of the closest-hit walk over the rays the lanes of a wave hold (`have`: this lane holds one; `node`: the record it
+// stands on, `end` or beyond once it has run out of tree): phase 1 walks nodes until enough lanes stand on a leaf whose box is
+// hit, phase 1b resolves the boxes the f32 tier left undecided, phase 2 tests the surfaces of the waiting lanes.
 // REC16 (trees in global memory only): the 16-byte quantised records (DNode16) instead of the 32-byte f32 ones.
+template <bool COUNT, bool LDS_NODES, bool BATCH, bool REC16>
+__device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& w, bool have, const V3& o, const V3& d, RayF32& rf, double tmin,
+                                          double& tmax, uint32_t& best_leaf, uint32_t& node, uint32_t end, uint32_t PEND_AT, bool scene_filter,
+                                          uint32_t& c_nodes, uint32_t& c_sph, uint32_t& c_pln, uint32_t& c_fallback, WalkProfile& prof) {
+    constexpr bool batch_undecided = BATCH;   // a separate instance of the kernel: with both forms in one loop the common one is 3 % slower
+    constexpr uint32_t REC_BYTES = REC16 ? 16u : 32u, REC_SHIFT = REC16 ? 4u : 5u;
+    bool pending = false;    // standing on a leaf whose box was hit, surface not tested yet
+    uint32_t leaf = NONE;
+    // ---- phase 1: walk to the next leaf whose box is hit
+    // A lane that found its leaf waits; so does a lane whose box test the f32 tier could not decide, at that node (the
+    // exact tiers run after the loop, for all such lanes together).  The loop also ends as soon as PEND_AT lanes are
+    // waiting, so a few long searches do not stall them.  The lane's state is one register: `at` is the record it stands
+    // on; it is `end` or beyond once the lane has nothing to walk (idle, out of tree), and carries WAIT or OPEN in its
+    // top bits while the lane waits on a leaf or on an undecided box.  With the state in flags the loop spent as many
+    // scalar instructions on who walks, waits or is done as vector instructions on the box test, and the scalar chain
+    // is what a step waits for.
+    constexpr uint32_t WAIT = 0x80000000u, OPEN = 0x40000000u;   // (records lie below 2^30: checked when the scene is created)
+    uint32_t n_pending = 0;   // wave-uniform
+    bool undecided = false;
+    uint32_t at = have ? node : end;
+    while (at < end) {        // lanes leave the loop one by one; the wave stays until all have left
+        // the record: six planes (f32, or grid steps as f32), whether it is a leaf, its surface code if so,
+        // and the byte offset of the record that follows its subtree
+        float planes[6];
+        bool is_leaf, contained = false;
+        uint32_t leaf_code, succ;
+        if (REC16) {
+            const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes16) + at);
+            planes[0] = (float)(r.x & 0xFFFFu); planes[1] = (float)(r.x >> 16);
+            planes[2] = (float)(r.y & 0xFFFFu); planes[3] = (float)(r.y >> 16);
+            planes[4] = (float)(r.z & 0xFFFFu); planes[5] = (float)(r.z >> 16);
+            is_leaf = r.w < NODE16_INTERNAL;
+            leaf_code = r.w;
+            succ = is_leaf ? at + 16u : r.w << 4;   // the tag bits shift out; a leaf is followed by the next record
+        } else {
+            uint4 n0, n1;
+            if (LDS_NODES) {
+                const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + at);
+                n0 = np[0];
+                n1 = np[1];
+            } else {
+                const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + at);
+                n0 = np[0];
+                n1 = np[1];
+            }
+            planes[0] = __uint_as_float(n0.x); planes[1] = __uint_as_float(n0.y); planes[2] = __uint_as_float(n0.z);
+            planes[3] = __uint_as_float(n0.w); planes[4] = __uint_as_float(n1.x); planes[5] = __uint_as_float(n1.y);
+            is_leaf = n1.w != NONE;
+            leaf_code = n1.w;
+            succ = BATCH ? (n1.z & ~31u) : n1.z;   // scenes of the BATCH form keep a flag in the (otherwise zero) low bits of a leaf's link
+            contained = BATCH && (n1.z & 1u) != 0u;
+        }
+        if (COUNT) ++c_nodes;
+        bool hit;
+        bool decided = box_hit_tier1<REC16>(planes, rf, hit);
+        if (BATCH && !COUNT && !REC16) {
+            // A node whose surfaces all lie inside its box with a margin (flagged when the scene was created): a hit of one
+            // of them inside [tmin, tmax] implies that the box test passes, so where the f32 tier cannot decide the box the walk
+            // goes on as if it had passed.  If the reference culls the node, nothing below it is hit and the outcome is the
+            // reference's; only the numbers of box and surface tests can differ, so the counting instances do not take this path.
+            const bool assume = !decided && contained && rf.tmin32 < rf.tmax32 && rf.K <= 3.0e38f;
+            hit = hit || assume;
+            decided = decided || assume;
+        }
+        // The lanes that start waiting in this step are counted from the comparisons' own masks (the ballot of a
+        // combined flag costs two vector instructions per step): f32 says hit (that implies decided) on a leaf ...
+        n_pending += (uint32_t)__popcll(ballot64(hit) & ballot64(is_leaf));
+        if (batch_undecided) n_pending += (uint32_t)__popcll(ballot64(true) & ~ballot64(decided));   // ... or, where there are many, undecided
+        leaf = leaf_code;   // only read once the lane waits on this leaf; a lane that walks on overwrites it
+        const uint32_t down = is_leaf ? (succ | WAIT) : at + REC_BYTES;   // links are byte offsets; a leaf's successor is its miss link as well
+        const uint32_t next = hit ? down : succ;
+        at = decided ? next : (at | OPEN);
+#ifdef RTX_PROFILE_PHASES
+        ++prof.iters;
+#endif
+        if (n_pending >= PEND_AT) break;   // wave-uniform
+    }
+    if (have) {
+        pending = (at & WAIT) != 0u;
+        undecided = (at & OPEN) != 0u;
+        node = at & ~(WAIT | OPEN);
+    }
+    // ---- phase 1b: the boxes left undecided, for all such lanes together
+    if (undecided) {
+#ifdef RTX_PROFILE_PHASES
+        ++prof.fb_iters;
+#endif
+        bool is_leaf;
+        uint32_t leaf_code, succ;
+        if (REC16) {
+            const uint32_t link = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes16) + node)->w;
+            is_leaf = link < NODE16_INTERNAL;
+            leaf_code = link;
+            succ = is_leaf ? node + 16u : link << 4;
+        } else {
+            const uint4 n1 = LDS_NODES ? reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + node)[1]
+                                       : reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + node)[1];
+            is_leaf = n1.w != NONE;
+            leaf_code = n1.w;
+            succ = BATCH ? (n1.z & ~31u) : n1.z;
+        }
+        const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> REC_SHIFT));
+        const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
+        if (COUNT) ++c_fallback;
+        const bool hit = tier2_box(q0, q1, q2, o, d, tmin, tmax, scene_filter);
+        pending = hit && is_leaf;
+        node = (hit && !is_leaf) ? node + REC_BYTES : succ;
+        leaf = pending ? leaf_code : leaf;
+        undecided = false;
+    }
+    PT(p1);
+
+    // ---- phase 2: surface tests of the lanes standing on a leaf
+    if (pending) {
+        const uint32_t kind = code_geom(leaf), slot = code_slot(leaf);
+        double t;
+        bool ph;
+        if (kind == 0u) {
+            if (COUNT) ++c_sph;
+            double2 sa, sb;
+            if (LDS_NODES && w.lds_surfaces) {   // wave-uniform: a branch, not a per-lane choice between two address spaces
+                typedef __attribute__((address_space(3))) const double* lds_ptr;   // keeps the two paths from being merged into one flat load
+                const lds_ptr spp = (lds_ptr)reinterpret_cast<const double*>(w.lds_spheres + 2u * slot);
+                sa = make_double2(spp[0], spp[1]);
+                sb = make_double2(spp[2], spp[3]);
+            } else {
+                const double2* spp = reinterpret_cast<const double2*>(sc.spheres + slot);
+                sa = spp[0];
+                sb = spp[1];
+            }
+            DSphere sp;
+            sp.c[0] = sa.x; sp.c[1] = sa.y; sp.c[2] = sb.x; sp.r = sb.y;
+            ph = sphere_t(sp, o, d, tmin, tmax, t);
+        } else {
+            if (COUNT) ++c_pln;
+            double al, be;
+            if (LDS_NODES && w.lds_surfaces) ph = planar_t(*reinterpret_cast<const DPlanar*>(w.lds_planars + 8u * slot), kind, o, d, tmin, tmax, t, al, be);
+            else ph = planar_t(sc.planars[slot], kind, o, d, tmin, tmax, t, al, be);
+        }
+        // `if let Some(nearest) = acc && hit.t > nearest.t { keep } else { replace }`
+        if (ph && !(best_leaf != NONE && t > tmax)) {
+            best_leaf = leaf;
+            tmax = t;   // shrunken_ray_t.max = hit.t
+            rayf32_set_tmax(rf, t);
+        }
+        pending = false;
+    }
+
+    PT(p2);
+}
+
 template <bool COUNT, bool LDS_NODES, bool SHARED, bool BATCH, bool REC16 = false>
 __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState& rays, const DHits& hits, const TraverseWork& w, double tmin,
                                                   double tmax0, DRenderCtl* ctl, WorkCounters& wc) {
@@ -562,10 +727,8 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
     bool list_done = p_end == 0u;
     uint32_t next_p = 0;   // !SHARED: next position of the wave's own list
     const bool scene_filter = sc.filter_ok != 0u;
-    constexpr bool batch_undecided = BATCH;   // a separate instance of the kernel: with both forms in one loop the common one is 3 % slower
     static_assert(!(REC16 && LDS_NODES), "the quantised records are for trees that do not fit in LDS");
-    constexpr uint32_t REC_BYTES = REC16 ? 16u : 32u, REC_SHIFT = REC16 ? 4u : 5u;
-    const uint32_t end = sc.n_nodes * REC_BYTES;   // nodes are addressed by the byte offset of their record
+    const uint32_t end = sc.n_nodes * (REC16 ? 16u : 32u);   // nodes are addressed by the byte offset of their record
 
     uint32_t idx = NONE;   // ray of this lane, NONE = idle
     V3 o = v3(0, 0, 0), d = v3(1, 1, 1);
@@ -575,15 +738,10 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
     if (REC16) rayq16_init(rf, o, d, tmin, tmax0, sc.q_org, sc.q_delta);
     else rayf32_init(rf, o, d, tmin, tmax0);
     uint32_t c_nodes = 0, c_sph = 0, c_pln = 0, c_fallback = 0;
-    bool pending = false;    // standing on a leaf whose box was hit, surface not tested yet
-    uint32_t leaf = NONE;
-
+    WalkProfile prof;
 #ifdef RTX_PROFILE_PHASES
-    long long pt_fb_iters = 0, pt_fb_cycles = 0, pt_refill = 0, pt_p1 = 0, pt_p2 = 0, pt_retire = 0, pt_iters = 0, pt_outer = 0, pt_mark = clock64();
-    const long long pt_begin = pt_mark, pt_wall_begin = wall_clock64();
-#define PT(acc) do { const long long now_ = clock64(); acc += now_ - pt_mark; pt_mark = now_; } while (0)
-#else
-#define PT(acc) do {} while (0)
+    prof.mark = clock64();
+    const long long pt_begin = prof.mark, pt_wall_begin = wall_clock64();
 #endif
     for (;;) {
         // ---- refill idle lanes from the wave's work list once enough of them are idle
@@ -619,176 +777,37 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
             }
         }
 
-        PT(pt_refill);
+        PT(refill);
 #ifdef RTX_PROFILE_PHASES
-        ++pt_outer;
+        ++prof.outer;
 #endif
-        // ---- phase 1: walk to the next leaf whose box is hit
-        // A lane that found its leaf waits; so does a lane whose box test the f32 tier could not decide, at that node (the
-        // exact tiers run after the loop, for all such lanes together).  The loop also ends as soon as PEND_AT lanes are
-        // waiting, so a few long searches do not stall them.  The lane's state is one register: `at` is the record it stands
-        // on; it is `end` or beyond once the lane has nothing to walk (idle, out of tree), and carries WAIT or OPEN in its
-        // top bits while the lane waits on a leaf or on an undecided box.  With the state in flags the loop spent as many
-        // scalar instructions on who walks, waits or is done as vector instructions on the box test, and the scalar chain
-        // is what a step waits for.
-        constexpr uint32_t WAIT = 0x80000000u, OPEN = 0x40000000u;   // (records lie below 2^30: checked when the scene is created)
-        uint32_t n_pending = 0;   // wave-uniform
-        bool undecided = false;
-        uint32_t at = idx != NONE ? node : end;
-        while (at < end) {        // lanes leave the loop one by one; the wave stays until all have left
-            // the record: six planes (f32, or grid steps as f32), whether it is a leaf, its surface code if so,
-            // and the byte offset of the record that follows its subtree
-            float planes[6];
-            bool is_leaf, contained = false;
-            uint32_t leaf_code, succ;
-            if (REC16) {
-                const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes16) + at);
-                planes[0] = (float)(r.x & 0xFFFFu); planes[1] = (float)(r.x >> 16);
-                planes[2] = (float)(r.y & 0xFFFFu); planes[3] = (float)(r.y >> 16);
-                planes[4] = (float)(r.z & 0xFFFFu); planes[5] = (float)(r.z >> 16);
-                is_leaf = r.w < NODE16_INTERNAL;
-                leaf_code = r.w;
-                succ = is_leaf ? at + 16u : r.w << 4;   // the tag bits shift out; a leaf is followed by the next record
-            } else {
-                uint4 n0, n1;
-                if (LDS_NODES) {
-                    const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + at);
-                    n0 = np[0];
-                    n1 = np[1];
-                } else {
-                    const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + at);
-                    n0 = np[0];
-                    n1 = np[1];
-                }
-                planes[0] = __uint_as_float(n0.x); planes[1] = __uint_as_float(n0.y); planes[2] = __uint_as_float(n0.z);
-                planes[3] = __uint_as_float(n0.w); planes[4] = __uint_as_float(n1.x); planes[5] = __uint_as_float(n1.y);
-                is_leaf = n1.w != NONE;
-                leaf_code = n1.w;
-                succ = BATCH ? (n1.z & ~31u) : n1.z;   // scenes of the BATCH form keep a flag in the (otherwise zero) low bits of a leaf's link
-                contained = BATCH && (n1.z & 1u) != 0u;
-            }
-            if (COUNT) ++c_nodes;
-            bool hit;
-            bool decided = box_hit_tier1<REC16>(planes, rf, hit);
-            if (BATCH && !COUNT && !REC16) {
-                // A node whose surfaces all lie inside its box with a margin (flagged when the scene was created): a hit of one
-                // of them inside [tmin, tmax] implies that the box test passes, so where the f32 tier cannot decide the box the walk
-                // goes on as if it had passed.  If the reference culls the node, nothing below it is hit and the outcome is the
-                // reference's; only the numbers of box and surface tests can differ, so the counting instances do not take this path.
-                const bool assume = !decided && contained && rf.tmin32 < rf.tmax32 && rf.K <= 3.0e38f;
-                hit = hit || assume;
-                decided = decided || assume;
-            }
-            // The lanes that start waiting in this step are counted from the comparisons' own masks (the ballot of a
-            // combined flag costs two vector instructions per step): f32 says hit (that implies decided) on a leaf ...
-            n_pending += (uint32_t)__popcll(ballot64(hit) & ballot64(is_leaf));
-            if (batch_undecided) n_pending += (uint32_t)__popcll(ballot64(true) & ~ballot64(decided));   // ... or, where there are many, undecided
-            leaf = leaf_code;   // only read once the lane waits on this leaf; a lane that walks on overwrites it
-            const uint32_t down = is_leaf ? (succ | WAIT) : at + REC_BYTES;   // links are byte offsets; a leaf's successor is its miss link as well
-            const uint32_t next = hit ? down : succ;
-            at = decided ? next : (at | OPEN);
-#ifdef RTX_PROFILE_PHASES
-            ++pt_iters;
-#endif
-            if (n_pending >= PEND_AT) break;   // wave-uniform
-        }
-        if (idx != NONE) {
-            pending = (at & WAIT) != 0u;
-            undecided = (at & OPEN) != 0u;
-            node = at & ~(WAIT | OPEN);
-        }
-        // ---- phase 1b: the boxes left undecided, for all such lanes together
-        if (undecided) {
-#ifdef RTX_PROFILE_PHASES
-            ++pt_fb_iters;
-#endif
-            bool is_leaf;
-            uint32_t leaf_code, succ;
-            if (REC16) {
-                const uint32_t link = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes16) + node)->w;
-                is_leaf = link < NODE16_INTERNAL;
-                leaf_code = link;
-                succ = is_leaf ? node + 16u : link << 4;
-            } else {
-                const uint4 n1 = LDS_NODES ? reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + node)[1]
-                                           : reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + node)[1];
-                is_leaf = n1.w != NONE;
-                leaf_code = n1.w;
-                succ = BATCH ? (n1.z & ~31u) : n1.z;
-            }
-            const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> REC_SHIFT));
-            const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
-            if (COUNT) ++c_fallback;
-            const bool hit = tier2_box(q0, q1, q2, o, d, tmin, tmax, scene_filter);
-            pending = hit && is_leaf;
-            node = (hit && !is_leaf) ? node + REC_BYTES : succ;
-            leaf = pending ? leaf_code : leaf;
-            undecided = false;
-        }
-        PT(pt_p1);
-
-        // ---- phase 2: surface tests of the lanes standing on a leaf
-        if (pending) {
-            const uint32_t kind = code_geom(leaf), slot = code_slot(leaf);
-            double t;
-            bool ph;
-            if (kind == 0u) {
-                if (COUNT) ++c_sph;
-                double2 sa, sb;
-                if (LDS_NODES && w.lds_surfaces) {   // wave-uniform: a branch, not a per-lane choice between two address spaces
-                    typedef __attribute__((address_space(3))) const double* lds_ptr;   // keeps the two paths from being merged into one flat load
-                    const lds_ptr spp = (lds_ptr)reinterpret_cast<const double*>(w.lds_spheres + 2u * slot);
-                    sa = make_double2(spp[0], spp[1]);
-                    sb = make_double2(spp[2], spp[3]);
-                } else {
-                    const double2* spp = reinterpret_cast<const double2*>(sc.spheres + slot);
-                    sa = spp[0];
-                    sb = spp[1];
-                }
-                DSphere sp;
-                sp.c[0] = sa.x; sp.c[1] = sa.y; sp.c[2] = sb.x; sp.r = sb.y;
-                ph = sphere_t(sp, o, d, tmin, tmax, t);
-            } else {
-                if (COUNT) ++c_pln;
-                double al, be;
-                if (LDS_NODES && w.lds_surfaces) ph = planar_t(*reinterpret_cast<const DPlanar*>(w.lds_planars + 8u * slot), kind, o, d, tmin, tmax, t, al, be);
-                else ph = planar_t(sc.planars[slot], kind, o, d, tmin, tmax, t, al, be);
-            }
-            // `if let Some(nearest) = acc && hit.t > nearest.t { keep } else { replace }`
-            if (ph && !(best_leaf != NONE && t > tmax)) {
-                best_leaf = leaf;
-                tmax = t;   // shrunken_ray_t.max = hit.t
-                rayf32_set_tmax(rf, t);
-            }
-            pending = false;
-        }
-
-        PT(pt_p2);
+        walk_pass<COUNT, LDS_NODES, BATCH, REC16>(sc, w, idx != NONE, o, d, rf, tmin, tmax, best_leaf, node, end, PEND_AT, scene_filter, c_nodes, c_sph,
+                                                  c_pln, c_fallback, prof);
         // ---- retire rays that have run out of tree
         if (idx != NONE && node >= end) {
             st_stream(&hits.prim[idx], best_leaf);
             st_stream(&hits.t[idx], tmax);
             idx = NONE;
         }
-        PT(pt_retire);
+        PT(retire);
     }
 #ifdef RTX_PROFILE_PHASES
     if (lane == 0 && ctl && p_end > 0) {
         unsigned long long* pr = reinterpret_cast<unsigned long long*>(ctl + 1);   // debug area behind the control block
-        atomicAdd(pr + 0, (unsigned long long)pt_refill);
-        atomicAdd(pr + 1, (unsigned long long)pt_p1);
-        atomicAdd(pr + 2, (unsigned long long)pt_p2);
-        atomicAdd(pr + 3, (unsigned long long)pt_retire);
-        atomicAdd(pr + 4, (unsigned long long)pt_iters);
-        atomicAdd(pr + 5, (unsigned long long)pt_outer);
+        atomicAdd(pr + 0, (unsigned long long)prof.refill);
+        atomicAdd(pr + 1, (unsigned long long)prof.p1);
+        atomicAdd(pr + 2, (unsigned long long)prof.p2);
+        atomicAdd(pr + 3, (unsigned long long)prof.retire);
+        atomicAdd(pr + 4, (unsigned long long)prof.iters);
+        atomicAdd(pr + 5, (unsigned long long)prof.outer);
         atomicAdd(pr + 6, (unsigned long long)(clock64() - pt_begin));
         atomicAdd(pr + 7, 1ull);
         atomicAdd(pr + 8, (unsigned long long)(wall_clock64() - pt_wall_begin));
         atomicMax(pr + 9, (unsigned long long)(wall_clock64() - pt_wall_begin));
-        atomicMax(pr + 10, (unsigned long long)pt_iters);
-        atomicMax(pr + 11, (unsigned long long)pt_p1);
-        atomicAdd(pr + 12, (unsigned long long)pt_fb_iters);
-        atomicAdd(pr + 13, (unsigned long long)pt_fb_cycles);
+        atomicMax(pr + 10, (unsigned long long)prof.iters);
+        atomicMax(pr + 11, (unsigned long long)prof.p1);
+        atomicAdd(pr + 12, (unsigned long long)prof.fb_iters);
+        atomicAdd(pr + 13, (unsigned long long)prof.fb_cycles);
     }
 #endif
     if (COUNT) {
@@ -1047,6 +1066,132 @@ __device__ __forceinline__ void row_tail(unsigned long long add_x, unsigned long
         : "memory");
 }
 
+// What one bounce does to the rays a wave holds (`active`: this lane holds one): emitted light and the sky for the rays that
+// end here (`add`, `radiance`: to be added to the ray's pixel) and Material::scatter for the others (`alive`: the path goes on
+// from `p` along `nd` with `beta`, `draw` and `depth`).  Must be called by all 64 lanes: Vector3::random_unit is run for the wave.
+struct Bounce {
+    bool alive, add;
+    V3 p, nd, beta, radiance;
+    uint32_t draw, depth;
+};
+__device__ __forceinline__ Bounce bounce_wave(const DScene& sc, const uint4* lds_recs, uint64_t seed, uint32_t max_depth, V3 background, bool active,
+                                              uint32_t handle, double t, V3 o, V3 d, V3 beta, uint32_t pixel, uint32_t sample, uint32_t draw0,
+                                              uint32_t depth0) {
+    bool alive = false;
+    V3 p = v3(0, 0, 0), nd = v3(0, 0, 0);
+    uint32_t draw = 0, depth = 0;
+    // the record of the surface that was hit: requested as soon as the hit is known, so that it arrives during the sampling below
+    double2 r0 = make_double2(0, 0), r1 = r0, r2 = r0, r3 = r0;
+    if (active && handle != NONE) {
+        const uint32_t rec = code_geom(handle) != 0u ? sc.n_spheres + code_slot(handle) : code_slot(handle);
+        if (lds_recs) {   // wave-uniform
+            typedef __attribute__((address_space(3))) const double* lds_ptr;
+            const lds_ptr rp = (lds_ptr)reinterpret_cast<const double*>(lds_recs + 4u * rec);
+            r0 = make_double2(rp[0], rp[1]); r1 = make_double2(rp[2], rp[3]); r2 = make_double2(rp[4], rp[5]); r3 = make_double2(rp[6], rp[7]);
+        } else {
+            const double2* rp = reinterpret_cast<const double2*>(sc.shade_recs + rec);
+            r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
+        }
+    }
+    // Material::scatter (material.rs:20-33) is one sampling event: it starts on a block boundary of the path's
+    // stream.  Lambertian and Metal both start with Vector3::random_unit() (material.rs:62, :86), run here for the wave.
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t draw_ev = (draw0 + 1u) & ~1u;
+    V3 ru_cand;
+    uint32_t ru_trials;
+    random_unit_wave(active && handle != NONE && code_mat(handle) <= 1u, k0, k1, pixel, sample, draw_ev >> 1, ru_cand, ru_trials);
+    V3 radiance = v3(0.0, 0.0, 0.0);
+    bool add = false;
+    if (active) {
+        if (handle == NONE) {
+            radiance = beta * background;   // camera.rs:207
+            add = true;
+        } else {
+            const uint32_t mkind = code_mat(handle), slot = code_slot(handle);
+            const bool planar = code_geom(handle) != 0u;
+            const V3 rec_a = v3(r0.x, r0.y, r1.x);
+            const V3 rgb = v3(r2.x, r2.y, r3.x);
+            const double param = r3.y;
+            // complete the Hit for the winning surface (geometry.rs:232-249, 280-288)
+            p = o + d * t;
+            V3 outward;
+            double alpha = 0.0, beta_uv = 0.0;
+            if (!planar) {
+                outward = (p - rec_a) * r1.y;   // (p - center) / radius
+                if (mkind == 4u) {   // u,v only feed UVGradient
+                    const double2 uv = sphere_uv(p.x, p.y, p.z);
+                    alpha = uv.x;
+                    beta_uv = uv.y;
+                }
+            } else {
+                outward = rec_a;
+                if (mkind == 4u) {
+                    const DPlanar& g = sc.planars[slot];
+                    V3 qp = p - ld3(g.q);
+                    V3 w = ld3(g.w);
+                    alpha = dot(w, cross(qp, ld3(g.v)));
+                    beta_uv = dot(w, cross(ld3(g.u), qp));
+                }
+            }
+            const bool front_face = dot(d, outward) < 0.0;           // geometry.rs:135-145
+            const V3 n = front_face ? outward : -outward;
+
+            // Material::emitted, material.rs:35-54
+            if (mkind == 3u) {
+                radiance = beta * rgb;
+                add = true;
+            } else if (mkind == 4u) {
+                double a0 = 0.0 - alpha, a1 = 1.0 - alpha, b0 = 0.0 - beta_uv, b1 = 1.0 - beta_uv;
+                V3 e = v3(1.0 - sqrt(a0 * a0 + b0 * b0), 1.0 - sqrt(a1 * a1 + b0 * b0), 1.0 - sqrt(a0 * a0 + b1 * b1)) * param;
+                radiance = beta * e;
+                add = true;
+            }
+
+            // Material::scatter, material.rs:20-33
+            bool scattered = false;
+            V3 att = v3(1.0, 1.0, 1.0);
+            if (mkind <= 1u) {
+                const V3 ru = ru_cand / sqrt(length_squared(ru_cand));
+                draw_ev += 2u * ru_trials;
+                att = rgb;
+                if (mkind == 0u) {        // lambertian, material.rs:61-73
+                    V3 direction = n + ru;
+                    if (is_near_zero(direction)) direction = n;
+                    nd = direction;
+                    scattered = true;
+                } else {                   // metal, material.rs:84-96
+                    V3 reflected = reflect(d, n);
+                    V3 fuzz = ru * param;
+                    V3 fuzzed = to_unit(reflected) + fuzz;
+                    nd = fuzzed;
+                    scattered = dot(fuzzed, n) > 0.0;
+                }
+            } else if (mkind == 2u) {     // dielectric, material.rs:108-130
+                V3 r_in = to_unit(d);
+                double eta = front_face ? 1.0 / param : param;
+                double cos_theta = clampd(dot(-r_in, n), -1.0, 1.0);
+                double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+                bool refl = eta * sin_theta > 1.0;
+                if (!refl) {   // no draw on total internal reflection
+                    refl = reflectance(cos_theta, eta) > first_uniform_of_block(k0, k1, pixel, sample, draw_ev >> 1);
+                    ++draw_ev;
+                }
+                nd = refl ? reflect(r_in, n) : refract(r_in, n, eta);
+                scattered = true;
+            }
+            depth = depth0 + 1u;
+            if (scattered && depth < max_depth) {
+                beta = beta * att;
+                draw = draw_ev;
+                alive = true;
+            }
+        }
+    }
+    Bounce out;
+    out.alive = alive; out.add = add; out.p = p; out.nd = nd; out.beta = beta; out.radiance = radiance; out.draw = draw; out.depth = depth;
+    return out;
+}
+
 // One step of ray_color (src/camera.rs:184-208) in its iterative form:
 //   miss            -> add beta * background, path ends
 //   hit             -> add beta * emitted; scatter ? (beta *= attenuation, new ray) : path ends
@@ -1084,9 +1229,7 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
     for (uint32_t t0 = 0; t0 < count; t0 += 64u) {
         const uint32_t off = t0 + lane;
         const uint32_t i = base + off;
-        bool alive = false;
-        V3 p = v3(0, 0, 0), nd = v3(0, 0, 0), beta = v3(0, 0, 0);
-        uint32_t draw = 0, depth = 0;
+        V3 beta = v3(0, 0, 0);
         uint32_t handle, pixel, sample, draw0, depth0 = 0;
         double t = 0.0;
         V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
@@ -1113,112 +1256,12 @@ __device__ __forceinline__ uint32_t shade_wave(const DScene& sc, const DCamera& 
                 draw_n = ld_stream(&cur.draw[i + 64u]);
             }
         }
-        // the record of the surface that was hit: requested as soon as the hit is known, so that it arrives during the sampling below
-        double2 r0 = make_double2(0, 0), r1 = r0, r2 = r0, r3 = r0;
-        if (off < count && handle != NONE) {
-            const uint32_t rec = code_geom(handle) != 0u ? sc.n_spheres + code_slot(handle) : code_slot(handle);
-            if (lds_recs) {   // wave-uniform
-                typedef __attribute__((address_space(3))) const double* lds_ptr;
-                const lds_ptr rp = (lds_ptr)reinterpret_cast<const double*>(lds_recs + 4u * rec);
-                r0 = make_double2(rp[0], rp[1]); r1 = make_double2(rp[2], rp[3]); r2 = make_double2(rp[4], rp[5]); r3 = make_double2(rp[6], rp[7]);
-            } else {
-                const double2* rp = reinterpret_cast<const double2*>(sc.shade_recs + rec);
-                r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
-            }
-        }
-        // Material::scatter (material.rs:20-33) is one sampling event: it starts on a block boundary of the path's
-        // stream.  Lambertian and Metal both start with Vector3::random_unit() (material.rs:62, :86), run here for the wave.
-        const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-        uint32_t draw_ev = (draw0 + 1u) & ~1u;
-        V3 ru_cand;
-        uint32_t ru_trials;
-        random_unit_wave(off < count && handle != NONE && code_mat(handle) <= 1u, k0, k1, pixel, sample, draw_ev >> 1, ru_cand, ru_trials);
-        V3 radiance = v3(0.0, 0.0, 0.0);
-        bool add = false;
+        const Bounce bo = bounce_wave(sc, lds_recs, seed, max_depth, background, off < count, handle, t, o, d, beta, pixel, sample, draw0, depth0);
+        const bool alive = bo.alive, add = bo.add;
+        const V3 p = bo.p, nd = bo.nd, radiance = bo.radiance;
+        const uint32_t draw = bo.draw, depth = bo.depth;
+        beta = bo.beta;
         if (off < count) {
-            if (handle == NONE) {
-                radiance = beta * background;   // camera.rs:207
-                add = true;
-            } else {
-                const uint32_t mkind = code_mat(handle), slot = code_slot(handle);
-                const bool planar = code_geom(handle) != 0u;
-                const V3 rec_a = v3(r0.x, r0.y, r1.x);
-                const V3 rgb = v3(r2.x, r2.y, r3.x);
-                const double param = r3.y;
-                // complete the Hit for the winning surface (geometry.rs:232-249, 280-288)
-                p = o + d * t;
-                V3 outward;
-                double alpha = 0.0, beta_uv = 0.0;
-                if (!planar) {
-                    outward = (p - rec_a) * r1.y;   // (p - center) / radius
-                    if (mkind == 4u) {   // u,v only feed UVGradient
-                        const double2 uv = sphere_uv(p.x, p.y, p.z);
-                        alpha = uv.x;
-                        beta_uv = uv.y;
-                    }
-                } else {
-                    outward = rec_a;
-                    if (mkind == 4u) {
-                        const DPlanar& g = sc.planars[slot];
-                        V3 qp = p - ld3(g.q);
-                        V3 w = ld3(g.w);
-                        alpha = dot(w, cross(qp, ld3(g.v)));
-                        beta_uv = dot(w, cross(ld3(g.u), qp));
-                    }
-                }
-                const bool front_face = dot(d, outward) < 0.0;           // geometry.rs:135-145
-                const V3 n = front_face ? outward : -outward;
-
-                // Material::emitted, material.rs:35-54
-                if (mkind == 3u) {
-                    radiance = beta * rgb;
-                    add = true;
-                } else if (mkind == 4u) {
-                    double a0 = 0.0 - alpha, a1 = 1.0 - alpha, b0 = 0.0 - beta_uv, b1 = 1.0 - beta_uv;
-                    V3 e = v3(1.0 - sqrt(a0 * a0 + b0 * b0), 1.0 - sqrt(a1 * a1 + b0 * b0), 1.0 - sqrt(a0 * a0 + b1 * b1)) * param;
-                    radiance = beta * e;
-                    add = true;
-                }
-
-                // Material::scatter, material.rs:20-33
-                bool scattered = false;
-                V3 att = v3(1.0, 1.0, 1.0);
-                if (mkind <= 1u) {
-                    const V3 ru = ru_cand / sqrt(length_squared(ru_cand));
-                    draw_ev += 2u * ru_trials;
-                    att = rgb;
-                    if (mkind == 0u) {        // lambertian, material.rs:61-73
-                        V3 direction = n + ru;
-                        if (is_near_zero(direction)) direction = n;
-                        nd = direction;
-                        scattered = true;
-                    } else {                   // metal, material.rs:84-96
-                        V3 reflected = reflect(d, n);
-                        V3 fuzz = ru * param;
-                        V3 fuzzed = to_unit(reflected) + fuzz;
-                        nd = fuzzed;
-                        scattered = dot(fuzzed, n) > 0.0;
-                    }
-                } else if (mkind == 2u) {     // dielectric, material.rs:108-130
-                    V3 r_in = to_unit(d);
-                    double eta = front_face ? 1.0 / param : param;
-                    double cos_theta = clampd(dot(-r_in, n), -1.0, 1.0);
-                    double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
-                    bool refl = eta * sin_theta > 1.0;
-                    if (!refl) {   // no draw on total internal reflection
-                        refl = reflectance(cos_theta, eta) > first_uniform_of_block(k0, k1, pixel, sample, draw_ev >> 1);
-                        ++draw_ev;
-                    }
-                    nd = refl ? reflect(r_in, n) : refract(r_in, n, eta);
-                    scattered = true;
-                }
-                depth = depth0 + 1u;
-                if (scattered && depth < max_depth) {
-                    beta = beta * att;
-                    draw = draw_ev;
-                    alive = true;
-                }
-            }
             if (!DEEP && add) {
                 double* px = accum + 3 * (size_t)pixel;
                 if (radiance.x != 0.0) unsafeAtomicAdd(px + 0, radiance.x);
@@ -1311,7 +1354,7 @@ __device__ __forceinline__ DScene uniform_scene(const DScene& s) {
     u.nodes32 = uniform_p(s.nodes32);
     u.nodes16 = uniform_p(s.nodes16);
     u.boxes64 = uniform_p(s.boxes64); u.shade_recs = uniform_p(s.shade_recs); u.rec_user_id = uniform_p(s.rec_user_id);
-    u.n_nodes = uniform32(s.n_nodes); u.filter_ok = uniform32(s.filter_ok); u.batch_undecided = uniform32(s.batch_undecided); u.pend_at = uniform32(s.pend_at); u.refill_at = uniform32(s.refill_at);
+    u.n_nodes = uniform32(s.n_nodes); u.filter_ok = uniform32(s.filter_ok); u.batch_undecided = uniform32(s.batch_undecided); u.pend_at = uniform32(s.pend_at); u.refill_at = uniform32(s.refill_at); u.bounce_at = uniform32(s.bounce_at);
     u.n_spheres = uniform32(s.n_spheres); u.n_planars = uniform32(s.n_planars);
     return u;
 }
@@ -1361,6 +1404,29 @@ __device__ RTX_PHASE_INLINE uint32_t phase_shade(const DRenderParams* pp, uint32
     return shade_wave<DEEP>(uniform_scene(P->sc), P->cam, st, uniform_hits(P->hits), base, count, st, uniform64(P->seed), uniform_p(P->accum), lds_recs);
 }
 
+// The block's LDS copy of the scene: the f32 node records, then (lds_surfaces) the sphere and planar tables, then (lds_recs) the
+// shade records.  Called by every thread of the block; ends with a barrier.
+__device__ __forceinline__ void stage_scene_in_lds(const DRenderParams* P) {
+    extern __shared__ uint4 lds_nodes[];
+    const DScene& sc = P->sc;
+    const uint4* src = reinterpret_cast<const uint4*>(sc.nodes32);
+    for (uint32_t i = threadIdx.x; i < 2u * sc.n_nodes; i += blockDim.x) lds_nodes[i] = src[i];
+    if (P->lds_surfaces) {
+        uint4* dst_s = lds_nodes + 2u * sc.n_nodes;
+        const uint4* src_s = reinterpret_cast<const uint4*>(sc.spheres);
+        for (uint32_t i = threadIdx.x; i < 2u * sc.n_spheres; i += blockDim.x) dst_s[i] = src_s[i];
+        uint4* dst_p = dst_s + 2u * sc.n_spheres;
+        const uint4* src_p = reinterpret_cast<const uint4*>(sc.planars);
+        for (uint32_t i = threadIdx.x; i < 8u * sc.n_planars; i += blockDim.x) dst_p[i] = src_p[i];
+        if (P->lds_recs) {
+            uint4* dst_r = dst_p + 8u * sc.n_planars;
+            const uint4* src_r = reinterpret_cast<const uint4*>(sc.shade_recs);
+            for (uint32_t i = threadIdx.x; i < 4u * (sc.n_spheres + sc.n_planars); i += blockDim.x) dst_r[i] = src_r[i];
+        }
+    }
+    __syncthreads();
+}
+
 // WIDE: one block of 1024 threads per CU (four waves per SIMD instead of five, 128 registers each instead of 96) so that one LDS
 // copy of the tree AND the surface tables serves sixteen waves; for scenes whose tables fit in LDS that way but not five times over.
 // The fifth wave is given up for surface tests without a trip to memory and for the registers that let the shade phase read a whole
@@ -1368,26 +1434,7 @@ __device__ RTX_PHASE_INLINE uint32_t phase_shade(const DRenderParams* pp, uint32
 constexpr uint32_t WIDE_BLOCK = 1024;
 template <bool COUNT, bool LDS_NODES, bool BATCH, bool WIDE = false, bool REC16 = false>
 __global__ __launch_bounds__(WIDE ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK, WIDE ? 4 : RTX_PERSISTENT_WAVES) void k_render_persistent(const DRenderParams* P) {
-    extern __shared__ uint4 lds_nodes[];
-    if (LDS_NODES) {
-        const DScene& sc = P->sc;
-        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes32);
-        for (uint32_t i = threadIdx.x; i < 2u * sc.n_nodes; i += blockDim.x) lds_nodes[i] = src[i];
-        if (P->lds_surfaces) {
-            uint4* dst_s = lds_nodes + 2u * sc.n_nodes;
-            const uint4* src_s = reinterpret_cast<const uint4*>(sc.spheres);
-            for (uint32_t i = threadIdx.x; i < 2u * sc.n_spheres; i += blockDim.x) dst_s[i] = src_s[i];
-            uint4* dst_p = dst_s + 2u * sc.n_spheres;
-            const uint4* src_p = reinterpret_cast<const uint4*>(sc.planars);
-            for (uint32_t i = threadIdx.x; i < 8u * sc.n_planars; i += blockDim.x) dst_p[i] = src_p[i];
-            if (P->lds_recs) {
-                uint4* dst_r = dst_p + 8u * sc.n_planars;
-                const uint4* src_r = reinterpret_cast<const uint4*>(sc.shade_recs);
-                for (uint32_t i = threadIdx.x; i < 4u * (sc.n_spheres + sc.n_planars); i += blockDim.x) dst_r[i] = src_r[i];
-            }
-        }
-        __syncthreads();
-    }
+    if (LDS_NODES) stage_scene_in_lds(P);
     const uint32_t wave = uniform32((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_sub = uniform32(P->n_sub);
     if (wave >= n_sub) return;
@@ -1463,6 +1510,157 @@ __global__ __launch_bounds__(WIDE ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK, WIDE ? 4 
             atomicAdd(&ctl->planar_tests, wc.planars);
             atomicAdd(&ctl->box_fallbacks, wc.fallbacks);
         }
+    }
+}
+
+// ---------------------------------------------------------------- whole render in one launch, paths resident in registers
+// The same sample loop with nothing of a path in memory between bounces: a lane keeps its path (ray, attenuation, pixel, sample,
+// draw count, depth) in registers from the primary ray to the path's end and then starts the next path of the call in the same
+// registers.  The wave alternates between the closest-hit pass (walk_pass, as in the kernels above) and, once enough lanes have
+// finished their walk, one bounce for those lanes (bounce_wave) followed by new primary rays for the lanes whose paths ended.
+// There is no pool, no compaction and no hit record: per ray the kernel touches memory only to add finished paths into the
+// image, against ~300 bytes per ray of state the pooled form moves.  What it gives up: the bounce and the primary-ray code run for
+// the lanes that are ready (half to all of a wave) instead of for dense rows, and lanes wait for the batch to fill.  For scenes
+// whose tree, surface tables and shade records all sit in LDS (the WIDE form's case).
+template <bool BATCH>
+__global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRenderParams* Pin) {
+    extern __shared__ uint4 lds_nodes[];
+    __shared__ DCamera cam;   // read whenever lanes start new paths: from LDS, not through a pointer to memory
+    static_assert(sizeof(DCamera) % 4 == 0, "copied word by word");
+    for (uint32_t i = threadIdx.x; i < sizeof(DCamera) / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(&cam)[i] = reinterpret_cast<const uint32_t*>(&Pin->cam)[i];
+    stage_scene_in_lds(Pin);   // ends with a barrier
+    const DRenderParams* P = uniform_ptr(Pin);
+    const uint32_t wave = uniform32((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (wave >= uniform32(P->n_sub)) return;
+    const uint32_t lane = lane_id();
+    const DScene sc = uniform_scene(P->sc);
+    DRenderCtl* const ctl = uniform_p(P->ctl);
+    const unsigned long long total = uniform64(ctl->total_paths);
+    const unsigned long long npix = (unsigned long long)uniform32(P->cam.image_width) * uniform32(P->cam.image_height);
+    const uint64_t seed = uniform64(P->seed);
+    const uint32_t spp_begin = uniform32(P->spp_begin);
+    const uint32_t max_depth = uniform32(P->cam.max_depth);
+    const V3 background = v3(uniform_f64(P->cam.background[0]), uniform_f64(P->cam.background[1]), uniform_f64(P->cam.background[2]));
+    const double tmin = uniform_f64(P->tmin), tmax0 = uniform_f64(P->tmax0);
+    double* const accum = uniform_p(P->accum);
+    const uint4* lds_recs = lds_nodes + 2u * sc.n_nodes + 2u * sc.n_spheres + 8u * sc.n_planars;
+    TraverseWork w{};
+    w.lds_nodes = lds_nodes;
+    w.lds_spheres = lds_nodes + 2u * sc.n_nodes;
+    w.lds_planars = w.lds_spheres + 2u * sc.n_spheres;
+    w.lds_surfaces = 1u;
+    const uint32_t end = sc.n_nodes * 32u;
+    const uint32_t PEND_AT = sc.pend_at, BOUNCE_AT = sc.bounce_at;
+    const bool scene_filter = sc.filter_ok != 0u;
+
+    // the lane's path and the ray it is on
+    bool have = false;
+    V3 o = v3(0, 0, 0), d = v3(1, 1, 1), beta = v3(1, 1, 1);
+    uint32_t pixel = 0, sample = 0, draw = 0, depth = 0;
+    double tmax = tmax0;
+    uint32_t best_leaf = NONE, node = end;
+    RayF32 rf;
+    rayf32_init(rf, o, d, tmin, tmax0);
+    bool exhausted = false;   // every path of the call has been started or belongs to another wave (wave-uniform, as what follows)
+    bool drained = false;     // the call's counter has nothing left for this wave
+    unsigned long long chunk_next = 0, chunk_end = 0, left_estimate = total;   // the wave's chunk of path indices
+    const uint32_t n_waves = uniform32(P->n_sub);
+    unsigned long long n_rays = 0;
+    uint32_t events = 0;
+    uint32_t c_nodes = 0, c_sph = 0, c_pln = 0, c_fallback = 0;
+    WalkProfile prof;
+    for (;;) {
+        const bool walked = have && node >= end;   // the ray has its closest hit (or none): the path's next bounce is due
+        const uint32_t n_walked = (uint32_t)__popcll(ballot64(walked));
+        const unsigned long long empty = ballot64(!have);
+        const uint32_t n_empty = (uint32_t)__popcll(empty);
+        const uint32_t n_walking = 64u - n_walked - n_empty;
+        if (n_walking == 0u && n_walked == 0u && exhausted) break;
+        // A bounce is worth its instructions once enough lanes take part: those whose walk is over plus, while the call has paths
+        // left, the empty ones; towards the end of the call, half of the lanes that still hold a path.
+        const uint32_t ready = n_walked + (exhausted ? 0u : n_empty);
+        const uint32_t enough = exhausted ? (n_walked + n_walking + 1u) / 2u : BOUNCE_AT;
+        if (ready >= enough || n_walking == 0u) {
+            ++events;
+            bool fresh = false;   // the lane starts on a new ray
+            // ---- one bounce of the paths whose walk is over
+            const Bounce bo = bounce_wave(sc, lds_recs, seed, max_depth, background, walked, best_leaf, tmax, o, d, beta, pixel, sample, draw, depth);
+            if (walked) {
+                if (bo.add) {
+                    double* px = accum + 3 * (size_t)pixel;
+                    if (bo.radiance.x != 0.0) unsafeAtomicAdd(px + 0, bo.radiance.x);
+                    if (bo.radiance.y != 0.0) unsafeAtomicAdd(px + 1, bo.radiance.y);
+                    if (bo.radiance.z != 0.0) unsafeAtomicAdd(px + 2, bo.radiance.z);
+                }
+                if (bo.alive) {
+                    o = bo.p; d = bo.nd; beta = bo.beta; draw = bo.draw; depth = bo.depth;
+                    fresh = true;
+                } else {
+                    have = false;
+                }
+            }
+            // ---- the next paths of the call for the lanes without one
+            if (!exhausted) {
+                const unsigned long long vacant = ballot64(!have);
+                const uint32_t need = (uint32_t)__popcll(vacant);
+                if (need) {
+                    // The wave draws path indices from the call's counter a chunk at a time (one returning atomic on a single word
+                    // per bounce of every wave would be the whole chip's atomic rate several times over) and hands them out from
+                    // the chunk; chunks shrink towards the end of the call so that no wave is left with a long tail of its own.
+                    if (chunk_next == chunk_end && !drained) {
+                        unsigned long long want = left_estimate / ((unsigned long long)n_waves * 8ull);
+                        want = want < 64ull ? 64ull : want > 4096ull ? 4096ull : want;
+                        unsigned long long first = 0;
+                        if (lane == 0) first = atomicAdd(&ctl->next_path[0], want);
+                        first = uniform64(first);
+                        if (first >= total) {
+                            drained = true;
+                        } else {
+                            const unsigned long long rest = total - first;
+                            chunk_next = first;
+                            chunk_end = first + (rest < want ? rest : want);
+                            drained = rest <= want;
+                            left_estimate = rest;
+                        }
+                    }
+                    const unsigned long long in_chunk = chunk_end - chunk_next;
+                    const uint32_t got = in_chunk < need ? (uint32_t)in_chunk : need;
+                    const unsigned long long first = chunk_next;
+                    chunk_next += got;
+                    exhausted = drained && chunk_next == chunk_end;
+                    if (got) {   // wave-uniform
+                        const uint32_t r = rank_below(vacant, lane);
+                        const bool takes = !have && r < got;
+                        uint32_t new_pixel, sample_off;
+                        split_path_index<false>(first + (takes ? r : 0u), npix, new_pixel, sample_off);
+                        const uint32_t new_sample = spp_begin + sample_off;
+                        V3 no, nd;
+                        uint32_t new_draw;
+                        start_path_wave(cam, seed, takes, new_pixel, new_sample, no, nd, new_draw);
+                        if (takes) {
+                            o = no; d = nd; beta = v3(1.0, 1.0, 1.0);
+                            pixel = new_pixel; sample = new_sample; draw = new_draw; depth = 0u;
+                            have = true;
+                            fresh = true;
+                        }
+                    }
+                }
+            }
+            if (fresh) {
+                tmax = tmax0;
+                best_leaf = NONE;
+                node = 0u;
+                rayf32_init(rf, o, d, tmin, tmax0);
+            }
+            n_rays += (unsigned long long)__popcll(ballot64(fresh));
+        }
+        walk_pass<false, true, BATCH, false>(sc, w, have, o, d, rf, tmin, tmax, best_leaf, node, end, PEND_AT, scene_filter, c_nodes, c_sph, c_pln,
+                                             c_fallback, prof);
+    }
+    if (lane == 0) {
+        atomicAdd(&ctl->rays, n_rays);
+        atomicMax(&ctl->rounds_max, events);
     }
 }
 
@@ -1632,6 +1830,21 @@ void launch_render_persistent(const DRenderParams* params, const DRenderParams& 
         else if (batch) hipLaunchKernelGGL((k_render_persistent<false, false, true>), g, b, 0, s, params);
         else hipLaunchKernelGGL((k_render_persistent<false, false, false>), g, b, 0, s, params);
     }
+}
+// The resident form (k_render_resident): one 1024-thread block per CU like the WIDE form, for scenes it can take (see
+// resident_form_fits); 0 if the kernel cannot be resident with that much LDS.
+uint32_t resident_waves_per_cu(const DScene& sc) {
+    int nb = 0;
+    const size_t lds = persistent_lds_bytes(sc, 3u, true);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_resident<false>, WIDE_BLOCK, lds) != hipSuccess || nb < 1) return 0u;
+    return (uint32_t)nb * (WIDE_BLOCK / 64);
+}
+void launch_render_resident(const DRenderParams* params, const DRenderParams& host_params, hipStream_t s) {
+    const uint32_t block_waves = WIDE_BLOCK / 64;
+    dim3 g((host_params.n_sub + block_waves - 1) / block_waves), b(WIDE_BLOCK);
+    const size_t lds = persistent_lds_bytes(host_params.sc, 3u, true);
+    if (host_params.sc.batch_undecided != 0u) hipLaunchKernelGGL((k_render_resident<true>), g, b, lds, s, params);
+    else hipLaunchKernelGGL((k_render_resident<false>), g, b, lds, s, params);
 }
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_scale, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, in, n, scale, out);

@@ -314,6 +314,27 @@ def test_mid_size_scenes_in_the_one_block_per_cu_form(rt, oracle, n, kind, wide,
     assert np.array_equal(bits(acc.cpu().numpy() + 0.0), bits(want + 0.0))
 
 
+@pytest.mark.parametrize("form", ["resident", "pooled"])
+def test_paths_resident_in_registers_render_the_same_image(rt, oracle, form, monkeypatch):
+    """The render kernel that keeps every path in registers from bounce to bounce (scenes that sit in LDS whole) against the
+    oracle and against the pooled kernel: one sample per pixel bit for bit (with the rays counted), several samples up to the
+    order of the f64 sums, depth limits from 1 up, a frame with fewer paths than one wave has lanes, and a soup of 600 spheres."""
+    monkeypatch.setenv("RTX_RESIDENT", "1" if form == "resident" else "0")
+    surfaces, cam = S.cover_spheres()
+    for width, seed, sample in ((320, 1, 0), (200, 0xC0FFEE, 41), (7, 5, 3)):
+        got, st, want, ctr = render_pair(rt, oracle, surfaces, dict(cam, image_width=width), seed, sample, 1, iterative=True)
+        assert st.rays == ctr.rays and st.paths == ctr.paths
+        assert np.array_equal(bits(got + 0.0), bits(want + 0.0)), f"{np.count_nonzero(got != want)} values differ"
+    for max_depth in (1, 2, 7, 50):
+        got, st, want, ctr = render_pair(rt, oracle, surfaces, dict(cam, image_width=96, max_depth=max_depth), 3, 2, 4, iterative=True)
+        assert st.rays == ctr.rays
+        assert np.allclose(got, want, rtol=1e-13, atol=0)
+    soup, scam = S.synthetic_soup(n=600, kind="spheres", seed=7, image_width=192, samples_per_pixel=1)
+    got, st, want, ctr = render_pair(rt, oracle, soup, dict(scam, max_depth=6), 11, 0, 1, iterative=True)
+    assert st.rays == ctr.rays
+    assert np.array_equal(bits(got + 0.0), bits(want + 0.0))
+
+
 def test_depth_limit_and_pool_smaller_than_job(rt, oracle, monkeypatch):
     surfaces, cam = S.cornell_box()
     for max_depth in (1, 2, 7):
