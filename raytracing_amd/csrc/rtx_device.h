@@ -436,8 +436,9 @@ __device__ __forceinline__ bool filter_ray_ok(V3 o, V3 d, double tmin, double tm
 // ---------------------------------------------------------------- f32 first tier
 // The same predicate (hi* > tmin, lo* < tmax, lo* < hi*), first tried in
 // single precision.  Write u = 2^-24.  With
-//     b32 = RN32(b),  inv32 = RN32(1 / RN32(d)),  oi32 = RN32(RN32(o) * inv32)
-// (so inv32 = (1/d)(1 + di), |di| <= 2.001u, and oi32 = (o/d)(1 + do)(1 + di)(1 + dm)),
+//     b32 = RN32(b),  inv32 = recip32(RN32(d)),  oi32 = RN32(RN32(o) * inv32)
+// (recip32: within (1 + 2^-18)u of the reciprocal, see there; so inv32 = (1/d)(1 + di), |di| <= 2.001u, and
+// oi32 = (o/d)(1 + do)(1 + di)(1 + dm)),
 // the slab distance t~ = RN32(b32 * inv32 - oi32), one fused operation, satisfies
 //     |t~ - Q| <= |Q| 3.002u + |b/d| 1.001u + |o/d| 2.002u,        Q = (b - o)/d,
 // and with |b/d| <= |Q| + |o/d|, |Q| <= |t~| + |t~ - Q|, |o/d| <= |oi32|(1 + 3.01u):
@@ -462,6 +463,17 @@ __device__ __forceinline__ bool filter_ray_ok(V3 o, V3 d, double tmin, double tm
 // tier only if 1e-30 <= |inv32| <= 1e15 and |oi32| <= 1e15 on every axis and
 // 1e-30 <= tmin <= 1e15, and a scene only if every box plane is at most 1e15
 // in magnitude; otherwise K is +infinity and every visit is undecided.
+// 1/x for the tier's rays: the hardware's approximate reciprocal (v_rcp_f32, documented to 1 ulp; 2^-21 relative would
+// do) and one Newton step.  With e0 = 1 - x r0, |e0| <= 2^-21:  e = RN32(1 - x r0) (one fused operation) = e0 (1 + d1),
+// r1 = RN32(r0 + e r0) = RN32((1/x)(1 - e0)(1 + e0 (1 + d1))) = RN32((1/x)(1 - e0^2 + e0 d1 (1 - e0))), so
+// |r1 - 1/x| <= (1/x)(u + 2^-42 + 2^-45) for x and 1/x in the normal range (the tier admits 1e-30 <= |1/x| <= 1e15 only;
+// zero, infinite and NaN arguments give 0, infinity or NaN, which that check rejects).  Three instructions per
+// component instead of the ten of a correctly rounded division, at the refill of a wave's idle lanes, where they
+// are issued for half a wave.
+__device__ __forceinline__ float recip32(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
 struct RayF32 {
     float inv[3], oi[3];   // oi holds +o/d: t~ = fma(b32, inv, -oi)
     float K;               // 8.1u * OI + 2e-30, or +inf when the ray skips this tier
@@ -479,7 +491,7 @@ __device__ __forceinline__ void rayf32_init(RayF32& r, V3 o, V3 d, double tmin, 
     float oi_max = 0.0f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        r.inv[a] = 1.0f / dv[a];            // correctly rounded (no fast-math)
+        r.inv[a] = recip32(dv[a]);
         r.oi[a] = ov[a] * r.inv[a];
         const float ai = fabsf(r.inv[a]), ao = fabsf(r.oi[a]);
         ok = ok && ai >= 1e-30f && ai <= 1e15f && ao <= 1e15f;   // NaN fails every comparison
@@ -512,7 +524,7 @@ __device__ __forceinline__ void rayq16_init(RayF32& r, V3 o, V3 d, double tmin, 
     float c_max = 0.0f, d_max = 0.0f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float inv = 1.0f / dv[a];           // correctly rounded (no fast-math)
+        const float inv = recip32(dv[a]);
         r.inv[a] = q_delta[a] * inv;              // s
         r.oi[a] = ov[a] * inv;                    // c
         const float ai = fabsf(inv), ac = fabsf(r.oi[a]), as = fabsf(r.inv[a]);

@@ -1697,7 +1697,8 @@ __global__ void k_selftest_math(int op, const double* a, const double* b, uint64
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         if (op == 0) out[i] = a[i] / b[i];
         else if (op == 1) out[i] = sqrt(a[i]);
-        else if (op == 3) out[i] = (double)((float)a[i] / (float)b[i]);   // the f32 division the first box tier relies on
+        else if (op == 3) out[i] = (double)((float)a[i] / (float)b[i]);
+        else if (op == 4) out[i] = (double)recip32((float)b[i]);   // the reciprocal the first box tier relies on
         else out[i] = a[i] * (1.0 / b[i]);
     }
 }

@@ -75,6 +75,25 @@ def test_device_f32_division_is_correctly_rounded(rt):
     assert np.array_equal(bits(got)[~nan], bits(want)[~nan])
 
 
+def test_device_f32_reciprocal_of_the_box_tier_is_within_its_bound(rt):
+    # the single-precision tier of the box test takes inv32 = recip32(RN32(d)) (approximate reciprocal + one Newton step)
+    # to be within (1 + 2^-18) 2^-24 of the reciprocal, for the rays it admits: 1e-30 <= |inv32| <= 1e15
+    rng = np.random.default_rng(6)
+    n = 1 << 21
+    b = rng.normal(size=n) * 10.0 ** rng.uniform(-15, 30, n)
+    b[: n // 4] = rng.uniform(-4.0, 4.0, n // 4)          # where a path tracer's directions live
+    b[:8] = [3.0, -7.0, 1e-15, 1e30, 0.1, 1.0, -1.0, 2.0 ** -20]
+    x32 = b.astype(np.float32)
+    exact = 1.0 / x32.astype(np.float64)
+    keep = (np.abs(exact) >= 1e-30) & (np.abs(exact) <= 1e15)
+    got = rt.selftest_math(4, np.ones(n), b)
+    assert np.all(np.abs(got - exact)[keep] <= (1 + 2.0 ** -18) * 2.0 ** -24 * np.abs(exact)[keep])
+    assert got[5] == 1.0 and got[6] == -1.0 and got[7] == 2.0 ** 20
+    # arguments the tier must reject still come out as something its range check rejects (zero, infinity or NaN)
+    odd = rt.selftest_math(4, np.ones(4), np.array([0.0, np.inf, np.nan, 1e-300]))
+    assert all(not (1e-30 <= abs(v) <= 1e15) for v in odd)
+
+
 def test_filtered_quotient_error_bound(rt):
     # the filtered box test relies on |a * RN(1/b) - RN(a/b)| <= 3 * 2^-53 |a/b|
     rng = np.random.default_rng(1)

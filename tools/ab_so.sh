@@ -6,7 +6,7 @@ spp="$1"; rounds="$2"; shift 2
 for r in $(seq 1 "$rounds"); do
   for n in "$@"; do
     cp "abtmp/$n.so" raytracing_amd/librtx.so
-    timeout -k 10 200 python3 -u bench.py --no-cpu-baseline --steps 3 --warmup 1 --spp "$spp" 2>/dev/null | LABEL="$n" python3 -c '
+    timeout -k 10 200 python3 -u bench.py --no-cpu-baseline --no-pmc --steps 3 --warmup 1 --spp "$spp" 2>/dev/null | LABEL="$n" python3 -c '
 import json, os, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(os.environ["LABEL"], d["ms_per_step"], "ms", d["value"], "Mrays/s", flush=True)'
