@@ -245,6 +245,14 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
         }
         for (int a = 0; a < 3; ++a) r.rgb[a] = mt.rgb[a];
         r.param = mt.param;
+        if (mt.kind == RTX_DIELECTRIC) {
+            // A dielectric has no colour; its record carries what scatter would divide for on every bounce
+            // (material.rs:111, 134-136): 1 / ri, and Schlick's r0^2 for eta = 1 / ri (front face) and eta = ri.
+            const double eta_front = 1.0 / mt.param;
+            r.rgb[0] = eta_front;
+            r.rgb[1] = schlick_r0(eta_front);
+            r.rgb[2] = schlick_r0(mt.param);
+        }
         rec_user_id[ri] = prims[i].user_id;
     }
     bool f32_ok = true;

@@ -81,6 +81,11 @@ struct DMaterial {                              // enum Material, src/material.r
 //   planar: a = norm,   s unused
 // plus the material's colour and parameter.  Geometry and material KIND do not
 // need a load at all: they travel in the surface code.
+//   dielectric: rgb = (1 / ri, schlick_r0(1 / ri), schlick_r0(ri)): the two divisions of a glass bounce, done once
+__host__ __device__ inline double schlick_r0(double eta) {   // src/material.rs:135-136
+    double r0 = (1.0 - eta) / (1.0 + eta);
+    return r0 * r0;
+}
 struct DShadeRec {
     double a[3];
     double s;

@@ -879,9 +879,8 @@ __global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_trav
 
 // ---------------------------------------------------------------- shade
 // Schlick, src/material.rs:134-137; powi(5) = x * ((x*x)*(x*x))
-__device__ __forceinline__ double reflectance(double cos_theta, double refraction_index) {
-    double r0 = (1.0 - refraction_index) / (1.0 + refraction_index);
-    r0 = r0 * r0;
+// (r0 = schlick_r0(refraction_index) comes with the surface's record)
+__device__ __forceinline__ double reflectance(double cos_theta, double r0) {
     double x = 1.0 - cos_theta;
     double x2 = x * x;
     double x5 = x * (x2 * x2);
@@ -1150,8 +1149,16 @@ __device__ __forceinline__ Bounce bounce_wave(const DScene& sc, const uint4* lds
             // Material::scatter, material.rs:20-33
             bool scattered = false;
             V3 att = v3(1.0, 1.0, 1.0);
+            // One normalisation serves three materials: Vector3::random_unit's `candidate / lensq.sqrt()` (vector.rs:59-81) for
+            // Lambertian and Metal and Dielectric's `ray.direction.to_unit()` (material.rs:110) are the same operations,
+            // v * (1 / sqrt(v.v)), on different vectors, and a row of rays usually holds all three materials.
+            V3 unit = v3(0.0, 0.0, 0.0);
+            if (mkind <= 2u) {
+                const V3 v = mkind == 2u ? d : ru_cand;
+                unit = v / sqrt(length_squared(v));
+            }
             if (mkind <= 1u) {
-                const V3 ru = ru_cand / sqrt(length_squared(ru_cand));
+                const V3 ru = unit;
                 draw_ev += 2u * ru_trials;
                 att = rgb;
                 if (mkind == 0u) {        // lambertian, material.rs:61-73
@@ -1167,13 +1174,13 @@ __device__ __forceinline__ Bounce bounce_wave(const DScene& sc, const uint4* lds
                     scattered = dot(fuzzed, n) > 0.0;
                 }
             } else if (mkind == 2u) {     // dielectric, material.rs:108-130
-                V3 r_in = to_unit(d);
-                double eta = front_face ? 1.0 / param : param;
+                V3 r_in = unit;
+                double eta = front_face ? rgb.x : param;        // 1.0 / ri : ri
                 double cos_theta = clampd(dot(-r_in, n), -1.0, 1.0);
                 double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
                 bool refl = eta * sin_theta > 1.0;
                 if (!refl) {   // no draw on total internal reflection
-                    refl = reflectance(cos_theta, eta) > first_uniform_of_block(k0, k1, pixel, sample, draw_ev >> 1);
+                    refl = reflectance(cos_theta, front_face ? rgb.y : rgb.z) > first_uniform_of_block(k0, k1, pixel, sample, draw_ev >> 1);
                     ++draw_ev;
                 }
                 nd = refl ? reflect(r_in, n) : refract(r_in, n, eta);
