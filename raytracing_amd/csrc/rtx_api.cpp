@@ -656,6 +656,8 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         P.spp_begin = spp_begin;
         P.lds_surfaces = (mode == 2u || mode == 3u) ? 1u : 0u;
         P.lds_recs = lds_recs ? 1u : 0u;
+        // block-by-block pixel order for trees that are walked from global memory (mode 0)
+        P.tile_order = (cam->image_width % 32u == 0u && cam->image_height % 16u == 0u && !resident && env_u32("RTX_TILE_ORDER", mode == 0u ? 1u : 0u, true) != 0u) ? 1u : 0u;
         HIP_TRY(hipMemcpyAsync(pp->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));
 #ifdef RTX_PROFILE_PHASES
         HIP_TRY(hipMemsetAsync(pp->ctl.p + 1, 0, 7 * sizeof(DRenderCtl), s));

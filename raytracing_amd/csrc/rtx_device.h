@@ -193,7 +193,9 @@ struct DRenderParams {
     unsigned long long seed;
     double tmin, tmax0;
     uint32_t n_sub, cap, spp_begin, lds_surfaces;
-    uint32_t lds_recs, pad_[3];   // the shade records are in LDS as well (behind the surface tables)
+    uint32_t lds_recs;      // the shade records are in LDS as well (behind the surface tables)
+    uint32_t tile_order;    // path indices name pixels block by block (tiled_pixel) instead of row by row
+    uint32_t pad_[2];
 };
 
 // ---------------------------------------------------------------- Vector3 (src/vector.rs)
@@ -577,6 +579,74 @@ __device__ __forceinline__ bool sphere_t(const DSphere& s, V3 o, V3 d, double tm
     double root = (h - sqrtd) / a;
     if (!(tmin < root && root < tmax)) {       // Interval::surrounds, open
         root = (h + sqrtd) / a;
+        if (!(tmin < root && root < tmax)) return false;
+    }
+    t = root;
+    return true;
+}
+// The same test for a ray whose a = d.d and 1/a were prepared when the ray was taken up (ray_div_init): the walk tests
+// two spheres per ray on average, for a quarter of a wave at a time, and a test is mostly its square root and its two
+// divisions by a.
+//
+// Division and square root here are the compiler's own correctly rounded sequences with the range scaffolding left out:
+//   n / x:   r = rcp(x), two Newton steps on r (refined_rcp, once per ray), q0 = n r, rem = fma(-x, q0, n), q = fma(rem, r, q0);
+//   sqrt(x): y = rsq(x), g = x y, h = y / 2, one coupled step on (g, h), two corrections g += (x - g g) h.
+// The compiler wraps these in v_div_scale / v_div_fmas / v_div_fixup and ldexp / class tests, which move operands of
+// extreme magnitude into range by powers of two (exact) and patch zeros, infinities and NaNs.  With every operand and
+// intermediate in the normal range the bare sequence computes the same roundings, hence the same bits.  That holds
+// when 2^-300 <= a <= 2^300 (else ra = 0 marks the ray), 2^-500 <= disc <= 2^500 and |h| <= 2^300: then sqrtd is in
+// [2^-250, 2^250], h -+ sqrtd is zero or at least 2^-53 max(|h|, sqrtd) >= 2^-303 in magnitude, and quotients, residuals
+// and their products stay between 2^-700 and 2^700.  A test outside those bounds takes sphere_t's library forms
+// (a GPU test compares both sequences with the host's division and square root bit for bit).
+struct RayDiv {
+    double a, ra;   // d.d and its refined reciprocal, or ra = 0: use the library division
+};
+__device__ __forceinline__ double refined_rcp(double x) {
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double e0 = fma(-x, r0, 1.0);
+    const double r1 = fma(r0, e0, r0);
+    const double e1 = fma(-x, r1, 1.0);
+    return fma(r1, e1, r1);
+}
+__device__ __forceinline__ double div_refined(double n, double x, double rx) {
+    const double q0 = n * rx;
+    const double rem = fma(-x, q0, n);
+    return fma(rem, rx, q0);
+}
+__device__ __forceinline__ double sqrt_normal_range(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double e = fma(-g, g, x);
+    g = fma(e, h, g);
+    e = fma(-g, g, x);
+    return fma(e, h, g);
+}
+__device__ __forceinline__ void ray_div_init(RayDiv& rd, V3 d) {
+    rd.a = length_squared(d);
+    rd.ra = (rd.a >= 0x1.0p-300 && rd.a <= 0x1.0p300) ? refined_rcp(rd.a) : 0.0;
+}
+__device__ __forceinline__ bool sphere_t_ray(const DSphere& s, V3 o, V3 d, const RayDiv& rd, double tmin, double tmax, double& t) {
+    V3 oc = v3(s.c[0], s.c[1], s.c[2]) - o;
+    const double a = rd.a;
+    double h = dot(d, oc);
+    double c = length_squared(oc) - s.r * s.r;
+    double discriminant = h * h - a * c;
+    if (discriminant < 0.0) return false;
+    const bool bare = rd.ra != 0.0 && discriminant >= 0x1.0p-500 && discriminant <= 0x1.0p500 && fabs(h) <= 0x1.0p300;
+    double sqrtd, root;
+    if (bare) {
+        sqrtd = sqrt_normal_range(discriminant);
+        root = div_refined(h - sqrtd, a, rd.ra);
+    } else {
+        sqrtd = sqrt(discriminant);
+        root = (h - sqrtd) / a;
+    }
+    if (!(tmin < root && root < tmax)) {       // Interval::surrounds, open
+        root = bare ? div_refined(h + sqrtd, a, rd.ra) : (h + sqrtd) / a;
         if (!(tmin < root && root < tmax)) return false;
     }
     t = root;

@@ -265,16 +265,32 @@ __device__ __forceinline__ void split_path_index(unsigned long long g, unsigned 
     pixel = (run << 6) | (pos & 63u);
 }
 
+// Image order in blocks: position `pos` of the pixel order names the pixel at (pos & 7, (pos >> 3) & 7) of an 8 x 8 tile, tiles
+// run 4 x 2 inside blocks of 32 x 16 pixels and the blocks run along the image's rows.  A run of 64 paths then covers a square
+// of the image and the ~800 paths of a sub-pool one or two blocks, instead of strips one pixel high: rays that start together
+// walk the same part of a tree that is read from global memory.  Needs a width that is a multiple of 32 and a height that
+// is a multiple of 16 (checked by the caller); any bijection on the pixels renders the same image.
+__device__ __forceinline__ uint32_t tiled_pixel(uint32_t pos, uint32_t width) {
+    const uint32_t k = pos & 63u, run = pos >> 6, t = run & 7u, blk = run >> 3, per_row = width >> 5;
+    uint32_t by = (uint32_t)((float)blk / (float)per_row);   // blk < 2^23: off by at most one
+    if (by * per_row > blk) --by;
+    else if ((by + 1u) * per_row <= blk) ++by;
+    const uint32_t bx = blk - by * per_row;
+    const uint32_t x = (bx << 5) + ((t & 3u) << 3) + (k & 7u), y = (by << 4) + ((t >> 2) << 3) + (k >> 3);
+    return y * width + x;
+}
+
 // The wave starts paths first .. first + n_new - 1 in slots slot0 .. of `st`.
 template <bool SCRAMBLE>
 __device__ __forceinline__ void generate_wave(const DCamera& cam, const DState& st, uint32_t slot0, unsigned long long first, uint32_t n_new,
-                                              uint64_t seed, uint32_t spp_begin) {
+                                              uint64_t seed, uint32_t spp_begin, uint32_t tiled = 0u) {
     const unsigned long long npix = (unsigned long long)cam.image_width * cam.image_height;
     for (uint32_t i0 = 0; i0 < n_new; i0 += 64u) {   // whole rows: the lanes past the end help the others
         const uint32_t i = i0 + lane_id();
         const bool valid = i < n_new;
         uint32_t pixel, sample_off;
         split_path_index<SCRAMBLE>(first + (valid ? i : 0u), npix, pixel, sample_off);
+        if (!SCRAMBLE && tiled) pixel = tiled_pixel(pixel, cam.image_width);   // wave-uniform choice
         const uint32_t sample = spp_begin + sample_off;
         V3 o, d;
         uint32_t draw;
@@ -567,7 +583,7 @@ struct WalkProfile {};
 // hit, phase 1b resolves the boxes the f32 tier left undecided, phase 2 tests the surfaces of the waiting lanes.
 // REC16 (trees in global memory only): the 16-byte quantised records (DNode16) instead of the 32-byte f32 ones.
 template <bool COUNT, bool LDS_NODES, bool BATCH, bool REC16>
-__device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& w, bool have, const V3& o, const V3& d, RayF32& rf, double tmin,
+__device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& w, bool have, const V3& o, const V3& d, const RayDiv& rdiv, RayF32& rf, double tmin,
                                           double& tmax, uint32_t& best_leaf, uint32_t& node, uint32_t end, uint32_t PEND_AT, bool scene_filter,
                                           uint32_t& c_nodes, uint32_t& c_sph, uint32_t& c_pln, uint32_t& c_fallback, WalkProfile& prof) {
     constexpr bool batch_undecided = BATCH;   // a separate instance of the kernel: with both forms in one loop the common one is 3 % slower
@@ -698,7 +714,8 @@ __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& 
             }
             DSphere sp;
             sp.c[0] = sa.x; sp.c[1] = sa.y; sp.c[2] = sb.x; sp.r = sb.y;
-            ph = sphere_t(sp, o, d, tmin, tmax, t);
+            // (trees walked from global memory wait for memory, not for the ALUs: there the prepared division only costs registers)
+            ph = REC16 ? sphere_t(sp, o, d, tmin, tmax, t) : sphere_t_ray(sp, o, d, rdiv, tmin, tmax, t);
         } else {
             if (COUNT) ++c_pln;
             double al, be;
@@ -737,6 +754,8 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
     RayF32 rf;
     if (REC16) rayq16_init(rf, o, d, tmin, tmax0, sc.q_org, sc.q_delta);
     else rayf32_init(rf, o, d, tmin, tmax0);
+    RayDiv rdiv;
+    ray_div_init(rdiv, d);
     uint32_t c_nodes = 0, c_sph = 0, c_pln = 0, c_fallback = 0;
     WalkProfile prof;
 #ifdef RTX_PROFILE_PHASES
@@ -774,6 +793,7 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
                 node = 0;
                 if (REC16) rayq16_init(rf, o, d, tmin, tmax0, sc.q_org, sc.q_delta);
                 else rayf32_init(rf, o, d, tmin, tmax0);
+                if (!REC16 && sc.n_spheres) ray_div_init(rdiv, d);   // wave-uniform: scenes without spheres skip it
             }
         }
 
@@ -781,7 +801,7 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
 #ifdef RTX_PROFILE_PHASES
         ++prof.outer;
 #endif
-        walk_pass<COUNT, LDS_NODES, BATCH, REC16>(sc, w, idx != NONE, o, d, rf, tmin, tmax, best_leaf, node, end, PEND_AT, scene_filter, c_nodes, c_sph,
+        walk_pass<COUNT, LDS_NODES, BATCH, REC16>(sc, w, idx != NONE, o, d, rdiv, rf, tmin, tmax, best_leaf, node, end, PEND_AT, scene_filter, c_nodes, c_sph,
                                                   c_pln, c_fallback, prof);
         // ---- retire rays that have run out of tree
         if (idx != NONE && node >= end) {
@@ -1371,7 +1391,7 @@ __device__ RTX_PHASE_INLINE void phase_generate(const DRenderParams* pp, uint32_
     slot0 = uniform32(slot0);
     got = uniform32(got);
     first = uniform64(first);
-    generate_wave<false>(P->cam, uniform_state(P->st[parity]), slot0, first, got, uniform64(P->seed), uniform32(P->spp_begin));
+    generate_wave<false>(P->cam, uniform_state(P->st[parity]), slot0, first, got, uniform64(P->seed), uniform32(P->spp_begin), uniform32(P->tile_order));
 }
 template <bool COUNT, bool LDS_NODES, bool BATCH, bool REC16>
 __device__ RTX_PHASE_INLINE void phase_traverse(const DRenderParams* pp, uint32_t parity, uint32_t base, uint32_t count, WorkCounters* wc) {
@@ -1569,6 +1589,8 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
     uint32_t best_leaf = NONE, node = end;
     RayF32 rf;
     rayf32_init(rf, o, d, tmin, tmax0);
+    RayDiv rdiv;
+    ray_div_init(rdiv, d);
     bool exhausted = false;   // every path of the call has been started or belongs to another wave (wave-uniform, as what follows)
     bool drained = false;     // the call's counter has nothing left for this wave
     unsigned long long chunk_next = 0, chunk_end = 0, left_estimate = total;   // the wave's chunk of path indices
@@ -1659,10 +1681,11 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
                 best_leaf = NONE;
                 node = 0u;
                 rayf32_init(rf, o, d, tmin, tmax0);
+                if (sc.n_spheres) ray_div_init(rdiv, d);
             }
             n_rays += (unsigned long long)__popcll(ballot64(fresh));
         }
-        walk_pass<false, true, BATCH, false>(sc, w, have, o, d, rf, tmin, tmax, best_leaf, node, end, PEND_AT, scene_filter, c_nodes, c_sph, c_pln,
+        walk_pass<false, true, BATCH, false>(sc, w, have, o, d, rdiv, rf, tmin, tmax, best_leaf, node, end, PEND_AT, scene_filter, c_nodes, c_sph, c_pln,
                                              c_fallback, prof);
     }
     if (lane == 0) {
@@ -1706,6 +1729,8 @@ __global__ void k_selftest_math(int op, const double* a, const double* b, uint64
         else if (op == 1) out[i] = sqrt(a[i]);
         else if (op == 3) out[i] = (double)((float)a[i] / (float)b[i]);
         else if (op == 4) out[i] = (double)recip32((float)b[i]);   // the reciprocal the first box tier relies on
+        else if (op == 5) out[i] = div_refined(a[i], b[i], refined_rcp(b[i]));   // the sphere test's bare division and square root
+        else if (op == 6) out[i] = sqrt_normal_range(a[i]);
         else out[i] = a[i] * (1.0 / b[i]);
     }
 }

@@ -94,6 +94,27 @@ def test_device_f32_reciprocal_of_the_box_tier_is_within_its_bound(rt):
     assert all(not (1e-30 <= abs(v) <= 1e15) for v in odd)
 
 
+def test_bare_division_and_sqrt_of_the_sphere_test_are_correctly_rounded(rt):
+    # the walk's sphere test divides by a = d.d with the compiler's division sequence minus its range scaffolding, and takes
+    # the square root the same way; inside the ranges it admits, both must give the host's correctly rounded results
+    rng = np.random.default_rng(7)
+    n = 1 << 22
+    x = np.abs(rng.normal(size=n)) * 2.0 ** rng.integers(-299, 299, n)          # a: 2^-300 .. 2^300
+    x[: n // 2] = np.abs(rng.normal(size=n // 2)) * 10.0 ** rng.uniform(-3, 3, n // 2) + 1e-9   # where directions live
+    num = rng.normal(size=n) * 2.0 ** rng.integers(-300, 299, n)
+    num[: n // 2] = rng.normal(size=n // 2) * 10.0 ** rng.uniform(-6, 6, n // 2)
+    num[:4] = [0.0, 1.0, -1.0, 2.0 ** -303]
+    x[:4] = [3.0, 3.0, 7.0, 2.0 ** 300]
+    keep = (x >= 2.0 ** -300) & (x <= 2.0 ** 300) & ((num == 0.0) | ((np.abs(num) >= 2.0 ** -303) & (np.abs(num) <= 2.0 ** 301)))
+    got = rt.selftest_math(5, num, x)
+    assert np.array_equal(bits(got)[keep], bits(num / x)[keep])
+    d = np.abs(rng.normal(size=n)) * 2.0 ** rng.integers(-499, 499, n)
+    d[: n // 2] = np.abs(rng.normal(size=n // 2)) * 10.0 ** rng.uniform(-8, 8, n // 2)
+    d[:6] = [1.0, 2.0, 4.0, 2.0 ** -500, 2.0 ** 500, 0.25]
+    d = np.clip(d, 2.0 ** -500, 2.0 ** 500)
+    assert np.array_equal(bits(rt.selftest_math(6, d, d)), bits(np.sqrt(d)))
+
+
 def test_filtered_quotient_error_bound(rt):
     # the filtered box test relies on |a * RN(1/b) - RN(a/b)| <= 3 * 2^-53 |a/b|
     rng = np.random.default_rng(1)
