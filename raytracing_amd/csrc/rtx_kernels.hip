@@ -551,8 +551,32 @@ __global__ __launch_bounds__(BLOCK, RTX_TRAVERSE_WAVES) void k_traverse(DScene s
 // few thousand nodes), so a visit costs two LDS reads and no trip through the
 // vector cache.
 // Work list and scene staging of one wave of the closest-hit walk.
+// LDS address (the 32-bit offset inside the block's LDS) of a pointer into LDS, and the way back
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4* lds_u4_ptr;
+__device__ __forceinline__ uint4 lds_read_u4(uint32_t lds_addr, uint32_t index) {   // 16 bytes at LDS address lds_addr + 16 * index
+    const u32x4 v = ((lds_u4_ptr)(uintptr_t)lds_addr)[index];
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// Copies the f32 node records into LDS.  In the copy a record's link (byte offset of its successor in the table) becomes
+// the successor's LDS address: the walk then keeps LDS addresses, not offsets, and the address of a visit's two reads is
+// the lane's state itself instead of table + offset (one vector instruction of a visit's thirty).  The table starts on a
+// 16-byte boundary, so the flag that BATCH scenes keep in bit 0 of a link survives the addition.
+__device__ __forceinline__ void stage_nodes_in_lds(uint4* lds_nodes, const DNode32* nodes32, uint32_t n_nodes) {
+    const uint4* src = reinterpret_cast<const uint4*>(nodes32);
+    const uint32_t bias = lds_address(lds_nodes);
+    for (uint32_t i = threadIdx.x; i < 2u * n_nodes; i += blockDim.x) {
+        uint4 v = src[i];
+        if (i & 1u) v.z += bias;   // second half of a record: planes z, link, surface code
+        lds_nodes[i] = v;
+    }
+}
 struct TraverseWork {
     const uint4* lds_nodes;     // LDS copy of the f32 node records (LDS_NODES)
+    uint32_t lds_base;          // its LDS address: with LDS_NODES the walk's node positions are LDS addresses
     const uint4* lds_spheres;   // LDS copies of the surface tables (lds_surfaces)
     const uint4* lds_planars;
     uint32_t lds_surfaces;
@@ -619,9 +643,8 @@ __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& 
         } else {
             uint4 n0, n1;
             if (LDS_NODES) {
-                const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + at);
-                n0 = np[0];
-                n1 = np[1];
+                n0 = lds_read_u4(at, 0u);
+                n1 = lds_read_u4(at, 1u);
             } else {
                 const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + at);
                 n0 = np[0];
@@ -631,7 +654,7 @@ __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& 
             planes[3] = __uint_as_float(n0.w); planes[4] = __uint_as_float(n1.x); planes[5] = __uint_as_float(n1.y);
             is_leaf = n1.w != NONE;
             leaf_code = n1.w;
-            succ = BATCH ? (n1.z & ~31u) : n1.z;   // scenes of the BATCH form keep a flag in the (otherwise zero) low bits of a leaf's link
+            succ = BATCH ? (n1.z & ~15u) : n1.z;   // scenes of the BATCH form keep a flag in the (otherwise zero) low bits of a leaf's link
             contained = BATCH && (n1.z & 1u) != 0u;
         }
         if (COUNT) ++c_nodes;
@@ -677,13 +700,14 @@ __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& 
             leaf_code = link;
             succ = is_leaf ? node + 16u : link << 4;
         } else {
-            const uint4 n1 = LDS_NODES ? reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w.lds_nodes) + node)[1]
-                                       : reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + node)[1];
+            uint4 n1;
+            if (LDS_NODES) n1 = lds_read_u4(node, 1u);
+            else n1 = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + node)[1];
             is_leaf = n1.w != NONE;
             leaf_code = n1.w;
-            succ = BATCH ? (n1.z & ~31u) : n1.z;
+            succ = BATCH ? (n1.z & ~15u) : n1.z;
         }
-        const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + (node >> REC_SHIFT));
+        const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + ((node - (LDS_NODES ? w.lds_base : 0u)) >> REC_SHIFT));
         const double2 q0 = bp[0], q1 = bp[1], q2 = bp[2];
         if (COUNT) ++c_fallback;
         const bool hit = tier2_box(q0, q1, q2, o, d, tmin, tmax, scene_filter);
@@ -745,12 +769,14 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
     uint32_t next_p = 0;   // !SHARED: next position of the wave's own list
     const bool scene_filter = sc.filter_ok != 0u;
     static_assert(!(REC16 && LDS_NODES), "the quantised records are for trees that do not fit in LDS");
-    const uint32_t end = sc.n_nodes * (REC16 ? 16u : 32u);   // nodes are addressed by the byte offset of their record
+    // nodes are addressed by the byte offset of their record in the table, or (LDS_NODES) by the record's LDS address
+    const uint32_t root = LDS_NODES ? w.lds_base : 0u;
+    const uint32_t end = root + sc.n_nodes * (REC16 ? 16u : 32u);
 
     uint32_t idx = NONE;   // ray of this lane, NONE = idle
     V3 o = v3(0, 0, 0), d = v3(1, 1, 1);
     double tmax = tmax0;   // == t of the best hit so far once there is one
-    uint32_t best_leaf = NONE, node = 0;   // node: byte offset of the f32 record (index * 32)
+    uint32_t best_leaf = NONE, node = root;
     RayF32 rf;
     if (REC16) rayq16_init(rf, o, d, tmin, tmax0, sc.q_org, sc.q_delta);
     else rayf32_init(rf, o, d, tmin, tmax0);
@@ -790,7 +816,7 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
                 d = v3(ld_stream(&rays.dx[mine]), ld_stream(&rays.dy[mine]), ld_stream(&rays.dz[mine]));
                 tmax = tmax0;
                 best_leaf = NONE;
-                node = 0;
+                node = root;
                 if (REC16) rayq16_init(rf, o, d, tmin, tmax0, sc.q_org, sc.q_delta);
                 else rayf32_init(rf, o, d, tmin, tmax0);
                 if (!REC16 && sc.n_spheres) ray_div_init(rdiv, d);   // wave-uniform: scenes without spheres skip it
@@ -847,8 +873,7 @@ __global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_trav
     const uint4* lds_spheres = lds_nodes + 2u * sc.n_nodes;
     const uint4* lds_planars = lds_spheres + 2u * sc.n_spheres;
     if (LDS_NODES) {
-        const uint4* src = reinterpret_cast<const uint4*>(sc.nodes32);
-        for (uint32_t i = threadIdx.x; i < 2u * sc.n_nodes; i += blockDim.x) lds_nodes[i] = src[i];
+        stage_nodes_in_lds(lds_nodes, sc.nodes32, sc.n_nodes);
         if (lds_surfaces) {
             uint4* dst_s = lds_nodes + 2u * sc.n_nodes;
             const uint4* src_s = reinterpret_cast<const uint4*>(sc.spheres);
@@ -880,6 +905,7 @@ __global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_trav
     __syncthreads();
     TraverseWork w{};
     w.lds_nodes = lds_nodes;
+    w.lds_base = lds_address(lds_nodes);
     w.lds_spheres = lds_spheres;
     w.lds_planars = lds_planars;
     w.lds_surfaces = lds_surfaces;
@@ -1400,6 +1426,7 @@ __device__ RTX_PHASE_INLINE void phase_traverse(const DRenderParams* pp, uint32_
     parity = uniform32(parity);
     TraverseWork w{};
     w.lds_nodes = lds_nodes;
+    w.lds_base = uniform32(lds_address(lds_nodes));
     w.lds_spheres = lds_nodes + 2u * P->sc.n_nodes;
     w.lds_planars = w.lds_spheres + 2u * P->sc.n_spheres;
     w.lds_surfaces = P->lds_surfaces;
@@ -1436,8 +1463,7 @@ __device__ RTX_PHASE_INLINE uint32_t phase_shade(const DRenderParams* pp, uint32
 __device__ __forceinline__ void stage_scene_in_lds(const DRenderParams* P) {
     extern __shared__ uint4 lds_nodes[];
     const DScene& sc = P->sc;
-    const uint4* src = reinterpret_cast<const uint4*>(sc.nodes32);
-    for (uint32_t i = threadIdx.x; i < 2u * sc.n_nodes; i += blockDim.x) lds_nodes[i] = src[i];
+    stage_nodes_in_lds(lds_nodes, sc.nodes32, sc.n_nodes);
     if (P->lds_surfaces) {
         uint4* dst_s = lds_nodes + 2u * sc.n_nodes;
         const uint4* src_s = reinterpret_cast<const uint4*>(sc.spheres);
@@ -1574,10 +1600,11 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
     const uint4* lds_recs = lds_nodes + 2u * sc.n_nodes + 2u * sc.n_spheres + 8u * sc.n_planars;
     TraverseWork w{};
     w.lds_nodes = lds_nodes;
+    w.lds_base = uniform32(lds_address(lds_nodes));
     w.lds_spheres = lds_nodes + 2u * sc.n_nodes;
     w.lds_planars = w.lds_spheres + 2u * sc.n_spheres;
     w.lds_surfaces = 1u;
-    const uint32_t end = sc.n_nodes * 32u;
+    const uint32_t root = w.lds_base, end = root + sc.n_nodes * 32u;   // node positions are LDS addresses
     const uint32_t PEND_AT = sc.pend_at, BOUNCE_AT = sc.bounce_at;
     const bool scene_filter = sc.filter_ok != 0u;
 
@@ -1679,7 +1706,7 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
             if (fresh) {
                 tmax = tmax0;
                 best_leaf = NONE;
-                node = 0u;
+                node = root;
                 rayf32_init(rf, o, d, tmin, tmax0);
                 if (sc.n_spheres) ray_div_init(rdiv, d);
             }
