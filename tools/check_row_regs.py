@@ -69,8 +69,12 @@ def check(lines, name, a, b):
         errors.append("%s: the first row and the later rows are loaded into different registers" % name)
     load_lines = {i for i, _ in nt}
     last_wait = None
+    # The rows live between the first row's loads and the last inline-assembly block of the kernel (the wait for the last row);
+    # what follows the main loop (the sums of the work counters) may use any register.
+    asm_ends = [i for i, l in enumerate(body) if ";;#ASMEND" in l]
+    last_asm = asm_ends[-1] if asm_ends else len(body)
     for i, l in code:
-        if i < first[0][0]:
+        if i < first[0][0] or i > last_asm:
             continue
         if re.search(r"s_waitcnt vmcnt\((0|16)\)", l):
             last_wait = i
