@@ -594,7 +594,7 @@ __device__ __forceinline__ bool sphere_t(const DSphere& s, V3 o, V3 d, double tm
 // The compiler wraps these in v_div_scale / v_div_fmas / v_div_fixup and ldexp / class tests, which move operands of
 // extreme magnitude into range by powers of two (exact) and patch zeros, infinities and NaNs.  With every operand and
 // intermediate in the normal range the bare sequence computes the same roundings, hence the same bits.  That holds
-// when 2^-300 <= a <= 2^300 (else ra = 0 marks the ray), 2^-500 <= disc <= 2^500 and |h| <= 2^300: then sqrtd is in
+// when 2^-300 <= a <= 2^300 (else ra = 0 marks the ray), 2^-500 <= disc < 2^500 and |h| < 2^300: then sqrtd is in
 // [2^-250, 2^250], h -+ sqrtd is zero or at least 2^-53 max(|h|, sqrtd) >= 2^-303 in magnitude, and quotients, residuals
 // and their products stay between 2^-700 and 2^700.  A test outside those bounds takes sphere_t's library forms
 // (a GPU test compares both sequences with the host's division and square root bit for bit).
@@ -636,18 +636,26 @@ __device__ __forceinline__ bool sphere_t_ray(const DSphere& s, V3 o, V3 d, const
     double c = length_squared(oc) - s.r * s.r;
     double discriminant = h * h - a * c;
     if (discriminant < 0.0) return false;
-    const bool bare = rd.ra != 0.0 && discriminant >= 0x1.0p-500 && discriminant <= 0x1.0p500 && fabs(h) <= 0x1.0p300;
+    // The bounds as integer tests on the high words (biased exponents 523 .. 1523 hold 2^-500 .. 2^500; a NaN or a negative
+    // number fails the first, an infinite or NaN h the second), and one choice for all the lanes that are here: the library
+    // forms are right for every operand, so a wave with a single lane outside the bounds takes them for all.
+    const uint32_t disc_hi = (uint32_t)__double2hiint(discriminant), h_hi = (uint32_t)__double2hiint(h) & 0x7FFFFFFFu;
+    const bool bare = (uint32_t)__double2hiint(rd.ra) != 0u && disc_hi - (523u << 20) < (1000u << 20) && h_hi < (1323u << 20);
     double sqrtd, root;
-    if (bare) {
+    if (__builtin_amdgcn_ballot_w64(!bare) == 0ull) {   // wave-uniform
         sqrtd = sqrt_normal_range(discriminant);
         root = div_refined(h - sqrtd, a, rd.ra);
+        if (!(tmin < root && root < tmax)) {       // Interval::surrounds, open
+            root = div_refined(h + sqrtd, a, rd.ra);
+            if (!(tmin < root && root < tmax)) return false;
+        }
     } else {
         sqrtd = sqrt(discriminant);
         root = (h - sqrtd) / a;
-    }
-    if (!(tmin < root && root < tmax)) {       // Interval::surrounds, open
-        root = bare ? div_refined(h + sqrtd, a, rd.ra) : (h + sqrtd) / a;
-        if (!(tmin < root && root < tmax)) return false;
+        if (!(tmin < root && root < tmax)) {
+            root = (h + sqrtd) / a;
+            if (!(tmin < root && root < tmax)) return false;
+        }
     }
     t = root;
     return true;

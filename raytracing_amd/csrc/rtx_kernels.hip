@@ -746,8 +746,9 @@ __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& 
             if (LDS_NODES && w.lds_surfaces) ph = planar_t(*reinterpret_cast<const DPlanar*>(w.lds_planars + 8u * slot), kind, o, d, tmin, tmax, t, al, be);
             else ph = planar_t(sc.planars[slot], kind, o, d, tmin, tmax, t, al, be);
         }
-        // `if let Some(nearest) = acc && hit.t > nearest.t { keep } else { replace }`
-        if (ph && !(best_leaf != NONE && t > tmax)) {
+        // `if let Some(nearest) = acc && hit.t > nearest.t { keep } else { replace }`: tmax is nearest.t once there is a nearest,
+        // and a hit lies inside the interval, so t <= tmax here and the candidate always replaces (ties included)
+        if (ph) {
             best_leaf = leaf;
             tmax = t;   // shrunken_ray_t.max = hit.t
             rayf32_set_tmax(rf, t);
