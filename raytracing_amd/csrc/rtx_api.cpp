@@ -656,6 +656,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         P.spp_begin = spp_begin;
         P.lds_surfaces = (mode == 2u || mode == 3u) ? 1u : 0u;
         P.lds_recs = lds_recs ? 1u : 0u;
+        P.tail_in_registers = env_u32("RTX_TAIL_IN_REGISTERS", 1, true);
         // block-by-block pixel order for trees that are walked from global memory (mode 0)
         P.tile_order = (cam->image_width % 32u == 0u && cam->image_height % 16u == 0u && !resident && env_u32("RTX_TILE_ORDER", mode == 0u ? 1u : 0u, true) != 0u) ? 1u : 0u;
         HIP_TRY(hipMemcpyAsync(pp->ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, s));

@@ -195,7 +195,8 @@ struct DRenderParams {
     uint32_t n_sub, cap, spp_begin, lds_surfaces;
     uint32_t lds_recs;      // the shade records are in LDS as well (behind the surface tables)
     uint32_t tile_order;    // path indices name pixels block by block (tiled_pixel) instead of row by row
-    uint32_t pad_[2];
+    uint32_t tail_in_registers;   // the last row of rays of a wave finishes in registers (phase_tail)
+    uint32_t pad_[1];
 };
 
 // ---------------------------------------------------------------- Vector3 (src/vector.rs)

@@ -1459,6 +1459,85 @@ __device__ RTX_PHASE_INLINE uint32_t phase_shade(const DRenderParams* pp, uint32
     return shade_wave<DEEP>(uniform_scene(P->sc), P->cam, st, uniform_hits(P->hits), base, count, st, uniform64(P->seed), uniform_p(P->accum), lds_recs);
 }
 
+// The end of a call, for one wave: the call has no more paths to start and at most a row of rays is left in the wave's
+// sub-pool.  Those rays stay in the lanes' registers from here to the end of their paths: closest hit, bounce, closest hit ...
+// with nothing written to the pool in between.  Through the pool a round of a nearly empty sub-pool is five trips to memory
+// (rays in, hits out, hits and state in, survivors out, each fenced), and the deepest path's rounds, one after the other, are the
+// tail every call ends with.  Returns the number of rays traced; results are those of the pooled rounds bit for bit (the same
+// walk_pass and bounce_wave on the same rays).
+template <bool COUNT, bool LDS_NODES, bool BATCH, bool REC16>
+__device__ RTX_PHASE_INLINE unsigned long long phase_tail(const DRenderParams* pp, uint32_t parity, uint32_t base, uint32_t count, WorkCounters* wc) {
+    extern __shared__ uint4 lds_nodes[];
+    const DRenderParams* P = uniform_ptr(pp);
+    parity = uniform32(parity);
+    base = uniform32(base);
+    count = uniform32(count);
+    const DScene sc = uniform_scene(P->sc);
+    const DState st = uniform_state(P->st[parity]);
+    TraverseWork w{};
+    w.lds_nodes = lds_nodes;
+    w.lds_base = uniform32(lds_address(lds_nodes));
+    w.lds_spheres = lds_nodes + 2u * sc.n_nodes;
+    w.lds_planars = w.lds_spheres + 2u * sc.n_spheres;
+    w.lds_surfaces = uniform32(P->lds_surfaces);
+    const uint4* lds_recs = (LDS_NODES && uniform32(P->lds_recs)) ? lds_nodes + 2u * sc.n_nodes + 2u * sc.n_spheres + 8u * sc.n_planars : nullptr;
+    const double tmin = uniform_f64(P->tmin), tmax0 = uniform_f64(P->tmax0);
+    const uint64_t seed = uniform64(P->seed);
+    const uint32_t max_depth = uniform32(P->cam.max_depth);
+    const V3 background = v3(uniform_f64(P->cam.background[0]), uniform_f64(P->cam.background[1]), uniform_f64(P->cam.background[2]));
+    double* const accum = uniform_p(P->accum);
+    const uint32_t root = LDS_NODES ? w.lds_base : 0u;
+    const uint32_t end = root + sc.n_nodes * (REC16 ? 16u : 32u);
+    const bool scene_filter = sc.filter_ok != 0u;
+    const uint32_t lane = lane_id();
+
+    bool have = lane < count;
+    const uint32_t k = base + (have ? lane : 0u);
+    V3 o = v3(ld_stream(&st.ox[k]), ld_stream(&st.oy[k]), ld_stream(&st.oz[k]));
+    V3 d = v3(ld_stream(&st.dx[k]), ld_stream(&st.dy[k]), ld_stream(&st.dz[k]));
+    V3 beta = v3(ld_stream(&st.bx[k]), ld_stream(&st.by[k]), ld_stream(&st.bz[k]));
+    const uint32_t pixel = ld_stream(&st.pixel[k]), sample = ld_stream(&st.sample[k]);
+    uint32_t draw = ld_stream(&st.draw[k]), depth = ld_stream(&st.depth[k]);
+    unsigned long long n_rays = 0;
+    uint32_t c_nodes = 0, c_sph = 0, c_pln = 0, c_fallback = 0;
+    WalkProfile prof;
+    while (ballot64(have) != 0ull) {
+        double tmax = tmax0;
+        uint32_t best_leaf = NONE, node = root;
+        RayF32 rf;
+        if (REC16) rayq16_init(rf, o, d, tmin, tmax0, sc.q_org, sc.q_delta);
+        else rayf32_init(rf, o, d, tmin, tmax0);
+        RayDiv rdiv;
+        rdiv.a = rdiv.ra = 0.0;
+        if (!REC16 && sc.n_spheres) ray_div_init(rdiv, d);
+        n_rays += (unsigned long long)__popcll(ballot64(have));
+        while (ballot64(have && node < end) != 0ull)
+            walk_pass<COUNT, LDS_NODES, BATCH, REC16>(sc, w, have, o, d, rdiv, rf, tmin, tmax, best_leaf, node, end, sc.pend_at, scene_filter, c_nodes, c_sph,
+                                                      c_pln, c_fallback, prof);
+        const Bounce bo = bounce_wave(sc, lds_recs, seed, max_depth, background, have, best_leaf, tmax, o, d, beta, pixel, sample, draw, depth);
+        if (have) {
+            if (bo.add) {
+                double* px = accum + 3 * (size_t)pixel;
+                if (bo.radiance.x != 0.0) unsafeAtomicAdd(px + 0, bo.radiance.x);
+                if (bo.radiance.y != 0.0) unsafeAtomicAdd(px + 1, bo.radiance.y);
+                if (bo.radiance.z != 0.0) unsafeAtomicAdd(px + 2, bo.radiance.z);
+            }
+            if (bo.alive) {
+                o = bo.p; d = bo.nd; beta = bo.beta; draw = bo.draw; depth = bo.depth;
+            } else {
+                have = false;
+            }
+        }
+    }
+    if (COUNT) {
+        wc->nodes += c_nodes;
+        wc->spheres += c_sph;
+        wc->planars += c_pln;
+        wc->fallbacks += c_fallback;
+    }
+    return n_rays;
+}
+
 // The block's LDS copy of the scene: the f32 node records, then (lds_surfaces) the sphere and planar tables, then (lds_recs) the
 // shade records.  Called by every thread of the block; ends with a barrier.
 __device__ __forceinline__ void stage_scene_in_lds(const DRenderParams* P) {
@@ -1529,6 +1608,11 @@ __global__ __launch_bounds__(WIDE ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK, WIDE ? 4 
         if (count == 0u) break;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         PP(pp_gen);
+        if (exhausted && count <= 64u && uniform32(P->tail_in_registers)) {   // the last rays of this wave
+            n_rays += phase_tail<COUNT, LDS_NODES, BATCH, REC16>(P, parity, base, count, &wc);
+            rounds += 1u;
+            break;
+        }
         phase_traverse<COUNT, LDS_NODES, BATCH, REC16>(P, parity, base, count, &wc);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         PP(pp_trav);

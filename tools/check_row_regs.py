@@ -54,7 +54,19 @@ def kernels(lines):
 def check(lines, name, a, b):
     body = lines[a:b]
     code = [(i, l) for i, l in enumerate(body) if l.strip() and not l.strip().startswith(";")]
-    nt = [(i, l) for i, l in code if re.search(r"global_load_dword(x2)?\s.*off nt", l)]
+    # The rows live between the first row's loads and the kernel's last inline-assembly block that loads, waits, adds or stores (row_request, row_wait, row_tail);
+    # what follows in the text (the tail phase, the sums of the work counters) may use any register and has loads of its own.
+    last_asm, inside, row_block = len(body), False, False
+    for i, l in enumerate(body):   # inline-assembly blocks of row_request / row_wait / row_tail: they load, wait, add or store
+        if ";;#ASMSTART" in l:
+            inside, row_block = True, False
+        elif ";;#ASMEND" in l:
+            if inside and row_block:
+                last_asm = i
+            inside = False
+        elif inside and re.search(r"global_load_dword|s_waitcnt vmcnt|global_atomic_add_f64|global_store_dword", l):
+            row_block = True
+    nt = [(i, l) for i, l in code if i <= last_asm and re.search(r"global_load_dword(x2)?\s.*off nt", l)]
     if len(nt) != WALK_LOADS + 2 * ROW_LOADS:
         return ["%s: %d non-temporal loads, expected %d (has the kernel changed?)" % (name, len(nt), WALK_LOADS + 2 * ROW_LOADS)]
     first, again = nt[WALK_LOADS:WALK_LOADS + ROW_LOADS], nt[WALK_LOADS + ROW_LOADS:]
@@ -69,10 +81,6 @@ def check(lines, name, a, b):
         errors.append("%s: the first row and the later rows are loaded into different registers" % name)
     load_lines = {i for i, _ in nt}
     last_wait = None
-    # The rows live between the first row's loads and the last inline-assembly block of the kernel (the wait for the last row);
-    # what follows the main loop (the sums of the work counters) may use any register.
-    asm_ends = [i for i, l in enumerate(body) if ";;#ASMEND" in l]
-    last_asm = asm_ends[-1] if asm_ends else len(body)
     for i, l in code:
         if i < first[0][0] or i > last_asm:
             continue
