@@ -105,6 +105,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 // 64 lanes.  Returns the accepted candidate and the number of trials used.
 // Sampler: static V3 candidate(k0, k1, pixel, sample, blk); static bool accept(V3).
 struct UnitVectorTrial {   // one trial of Vector3::random_unit (the candidate is not normalised)
+    static constexpr uint32_t OWN_TRIALS = 2u;   // accepts 52 % of its candidates
     static __device__ __forceinline__ V3 candidate(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk) {
         return random_unit_candidate(k0, k1, pixel, sample, blk);
     }
@@ -114,6 +115,7 @@ struct UnitVectorTrial {   // one trial of Vector3::random_unit (the candidate i
     }
 };
 struct UnitDiskTrial {   // one trial of Vector3::random_in_unit_disk: x, y = random_range(-1.0..1.0) from the two words of a block
+    static constexpr uint32_t OWN_TRIALS = 1u;   // accepts 79 %
     static __device__ __forceinline__ V3 candidate(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t blk) {
         double u0, u1;
         uniforms_of_block(k0, k1, pixel, sample, blk, u0, u1);
@@ -136,6 +138,22 @@ __device__ __forceinline__ void rejection_wave(bool need, uint32_t k0, uint32_t 
             cand = c;
             used = 1u;
             unresolved = false;
+        }
+        if (Sampler::OWN_TRIALS == 2u) {
+            // A sampler that rejects about half of its candidates tries its second one in the same lane as well (the two
+            // blocks are independent instruction streams): a quarter of the lanes is then left for the shared rounds below, each of
+            // which costs more than a trial (nine cross-lane reads and the bookkeeping of who helps whom) and the wave's time
+            // to wait for them.
+            const V3 c1 = Sampler::candidate(k0, k1, pixel, sample, blk0 + 1u);
+            const bool ok1 = Sampler::accept(c1);
+            if (unresolved) {
+                tried = 2u;
+                if (ok1) {
+                    cand = c1;
+                    used = 2u;
+                    unresolved = false;
+                }
+            }
         }
     }
     unsigned long long U = ballot64(unresolved);
