@@ -452,10 +452,19 @@ __device__ __forceinline__ bool filter_ray_ok(V3 o, V3 d, double tmin, double tm
 // and with |b/d| <= |Q| + |o/d|, |Q| <= |t~| + |t~ - Q|, |o/d| <= |oi32|(1 + 3.01u):
 //     |t~ - Q| <= 4.01u (|t~| + |oi32|).
 // The reference's own quotient is RN64 of the difference over d, within
-// 2^-52 |Q| of Q.  So with M >= every |t~| of the node and OI >= every |oi32|
-// of the ray, max/min over the axes move lo and hi by at most
+// 2^-52 |Q| of Q.  Max and min over such values keep the bound of the value they
+// return: with c = 4.01u and OI >= every |oi32| of the ray, x + c|x| and x - c|x|
+// grow with x, so  max_i (t~_i + c|t~_i|) = lo~ + c|lo~|  and the exact lower
+// fold lies within c (|lo~| + OI) of lo~ = max of the three near distances
+// (each near distance, a min of two, by the same argument), whatever the other
+// distances of the node are; the same for hi~.  Clamping at tmin32 / tmax32 only
+// removes error (a fold beyond the clamp by more than its error is the clamp
+// exactly, one within it has the clamp's magnitude).  So with
+// M = max(|lo~ clamped|, |hi~ clamped|) the folds are off by at most
 //     E = 4.05u (M + OI) + 1e-30
 // (the absolute term covers planes and products below the f32 normal range).
+// (Until the bound was taken from lo~ and hi~ themselves M was the largest of the
+// node's six |t~|: two instructions more per visit and a wider margin.)
 // Let s1 = hi - tmin32, s2 = tmax32 - lo, s3 = hi - lo and
 // m = RN32(min(hi, tmax32) - max(lo, tmin32)) = RN32(min(s1, s2, s3, tmax32 - tmin32));
 // the fourth term is never negative (tmin <= tmax), so it cannot make m
@@ -517,8 +526,9 @@ __device__ __forceinline__ void rayf32_init(RayF32& r, V3 o, V3 d, double tmin, 
 // Per ray  s = RN32(RN32(delta) inv32)  and  c = RN32(RN32(o') inv32)  (relative errors at most 4.01u each: see the
 // f32 tier for inv32), and the slab distance is the single fused t~ = RN32(q s - c); q < 2^16 is exact in f32.  Then
 //     |t~ - (q delta - o')/d| <= u |t~| + 4.01u |q delta / d| + 4.01u |o'/d|  <=  5.03u |t~| + 8.04u |c|,
-// using |q delta / d| <= |t~| + |t~ - ..| + |o'/d| and |o'/d| <= |c| (1 + 4.01u), and so with M >= every |t~| of the
-// node, C >= every |c| of the ray and D = max over the axes of RN32(delta) |inv32| (>= 2 |eps / d| / 1.0003):
+// using |q delta / d| <= |t~| + |t~ - ..| + |o'/d| and |o'/d| <= |c| (1 + 4.01u), and so with M = the larger of the two
+// clamped folds' magnitudes (a fold keeps the relative bound of the value it returns, as in the f32 tier),
+// C >= every |c| of the ray and D = max over the axes of RN32(delta) |inv32| (>= 2 |eps / d| / 1.0003):
 //     E = 5.05u M + 8.05u C + 0.5002 D + 1e-30     bounds the error of lo and hi.
 // The rest is the f32 tier's argument with this E: T = 14.2u M' + (16.2u C + 1.001 D + 2e-30) >= 2E + the rounding of
 // tmin, tmax and of the subtractions (4.1u M' as there).  m > T proves the reference's predicate true, m < -T false.
@@ -556,11 +566,10 @@ __device__ __forceinline__ bool box_hit_tier1(const float p[6], const RayF32& r,
     const float t0z = fmaf(p[4], r.inv[2], -r.oi[2]), t1z = fmaf(p[5], r.inv[2], -r.oi[2]);
     const float nx = fminf(t0x, t1x), ny = fminf(t0y, t1y), nz = fminf(t0z, t1z);
     const float fx = fmaxf(t0x, t1x), fy = fmaxf(t0y, t1y), fz = fmaxf(t0z, t1z);
-    const float lo = fmaxf(fmaxf(nx, ny), nz), hi = fminf(fminf(fx, fy), fz);
-    const float mn = fminf(fminf(nx, ny), nz), mx = fmaxf(fmaxf(fx, fy), fz);
-    const float M = fmaxf(fmaxf(-mn, mx), r.tg);
+    const float lo = fmaxf(fmaxf(fmaxf(nx, ny), nz), r.tmin32), hi = fminf(fminf(fminf(fx, fy), fz), r.tmax32);   // the folds, clamped
+    const float M = fmaxf(fmaxf(fabsf(lo), fabsf(hi)), r.tg);
     const float T = fmaf(M, Q16 ? TIER_Q16_COEF : TIER_F32_COEF, r.K);
-    const float m = fminf(hi, r.tmax32) - fmaxf(lo, r.tmin32);   // = min(s1, s2, s3, tmax32 - tmin32), one subtraction
+    const float m = hi - lo;   // = min(s1, s2, s3, tmax32 - tmin32), one subtraction
     hit = m > T;
     return fabsf(m) > T;   // T >= 0 (M >= 0: -mn or mx is; K >= 0), so this is m > T || m < -T in one comparison
 }
