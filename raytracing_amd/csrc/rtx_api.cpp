@@ -131,7 +131,7 @@ void rtx::pool_geometry(uint64_t need, uint32_t max_waves, uint32_t* n_sub, uint
 // 0: tree in global memory; 1: f32 node records in LDS; 2: node records and surface tables in LDS
 static uint32_t lds_mode_for(const rtx_scene* sc, uint32_t flags) {
     const uint32_t lds_limit = env_u32("RTX_LDS_SCENE_BYTES", 32u * 1024u);   // five blocks of the kernel per CU
-    const size_t tree = (size_t)sc->d.n_nodes * sizeof(DNode32);
+    const size_t tree = node_tables_lds_bytes(sc->d.n_nodes);
     const size_t surf = (size_t)sc->d.n_spheres * sizeof(DSphere) + (size_t)sc->d.n_planars * sizeof(DPlanar);
     if ((flags & RTX_FLAG_NO_LDS) || tree > lds_limit) return 0u;
     return tree + surf <= lds_limit ? 2u : 1u;
@@ -224,6 +224,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     // followed by the right child, the right child by the parent's successor.
     std::vector<DNode> nodes(n);
     std::vector<DNode32> nodes32(n);
+    std::vector<uint32_t> leaf_codes(n, NONE);
     std::vector<DBox64> boxes64(n);
     if (spheres.size() > CODE_SLOT_MASK || planars.size() > CODE_SLOT_MASK)
         return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: more than 2^27 - 1 surfaces of one kind");
@@ -287,14 +288,15 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
             nd.prim = code[prim];
             nd.kind = prims[prim].kind;
             nd.slot = prims[prim].slot;
-            nodes32[i].leaf = code[prim];
+            leaf_codes[i] = code[prim];
+            nodes32[i].down = ((i + 1u) * 32u) | NODE32_LEAF;
         } else {                  // Node::Internal(Some(right_idx), box)
             if (right == RTX_NONE || right <= i + 1 || right >= miss[i])
                 return fail(RTX_ERR_BAD_ARG, "rtx_scene_create: right child index out of order at node " + std::to_string(i));
             nd.prim = NONE;
             nd.kind = 0;
             nd.slot = 0;
-            nodes32[i].leaf = NONE;
+            nodes32[i].down = (i + 1u) * 32u;
             miss[i + 1] = right;
             miss[right] = miss[i];
         }
@@ -408,6 +410,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     UP(spheres, spheres);
     UP(planars, planars);
     UP(nodes32, nodes32);
+    UP(leaf_codes, leaf_codes);
     UP(nodes16, nodes16);
     UP(boxes64, boxes64);
     UP(rec_user_id, rec_user_id);
@@ -436,6 +439,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     sc->d.bounce_at = env_u32("RTX_BOUNCE_AT", 48u);
     if (sc->d.bounce_at > 64u) sc->d.bounce_at = 64u;
     sc->d.nodes32 = sc->nodes32.p;
+    sc->d.leaf_codes = sc->leaf_codes.p;
     sc->d.nodes16 = q16_ok ? sc->nodes16.p : nullptr;
     for (int a = 0; a < 3; ++a) {
         sc->d.q_org[a] = q_org[a];

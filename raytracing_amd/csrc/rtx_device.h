@@ -37,8 +37,16 @@ static_assert(sizeof(DNode) == 64, "node record must be one 64-byte line");
 struct __attribute__((aligned(32))) DNode32 {
     float plane[6];   // lo.x, hi.x, lo.y, hi.y, lo.z, hi.z
     uint32_t miss;    // DNode::miss as the byte offset of that node's record (index * 32)
-    uint32_t leaf;    // NONE for an internal node, else the surface code (make_code)
+    uint32_t down;    // where a ray whose box test passes goes: the next record (own offset + 32), with NODE32_LEAF set in a
+                      // leaf's (the ray then waits there for the surface test; a leaf's successor is the next record as well).
+                      // The step "hit ? down : miss" needs no test of what the node is, and no addition.
 };
+// LDS bytes of a tree's f32 records and, behind them, its leaf codes (padded to a 16-byte boundary)
+__host__ __device__ constexpr size_t node_tables_lds_bytes(uint32_t n_nodes) {
+    return (size_t)n_nodes * 32u + (((size_t)n_nodes * 4u + 15u) & ~(size_t)15u);
+}
+constexpr uint32_t NODE32_LEAF = 0x80000000u;   // records lie below 2^30 bytes (checked when the scene is created)
+// The surface code of a leaf is read after the walk's node loop, once per waiting lane, from DScene::leaf_codes (by node index).
 static_assert(sizeof(DNode32) == 32, "f32 node record must be 32 bytes");
 // Half-size copy of a node for trees that are walked from global memory (far larger than LDS and L2).  There the
 // walk is bound by how many lines the memory system can deliver per second (one request per visit that misses L2,
@@ -117,6 +125,7 @@ struct DScene {
     uint32_t refill_at;         // ... and gives idle lanes their next rays once this many lanes are idle
     uint32_t bounce_at;         // kernel with the paths in registers: one bounce once this many lanes have finished their walk or hold no path
     const DNode32* nodes32;
+    const uint32_t* leaf_codes;    // per node: the surface code of a leaf (make_code), NONE for an internal node
     const DBox64* boxes64;
     uint32_t n_spheres, n_planars;
     const DShadeRec* shade_recs;   // spheres by slot, then planars by slot

@@ -107,6 +107,7 @@ struct rtx_scene {
     rtx::DevBuf<rtx::DSphere> spheres;
     rtx::DevBuf<rtx::DPlanar> planars;
     rtx::DevBuf<rtx::DNode32> nodes32;
+    rtx::DevBuf<uint32_t> leaf_codes;
     rtx::DevBuf<rtx::DNode16> nodes16;
     rtx::DevBuf<rtx::DBox64> boxes64;
     rtx::DevBuf<uint32_t> rec_user_id;

@@ -583,15 +583,22 @@ __device__ __forceinline__ uint32_t lds_address(const void* p) {
 // the successor's LDS address: the walk then keeps LDS addresses, not offsets, and the address of a visit's two reads is
 // the lane's state itself instead of table + offset (one vector instruction of a visit's thirty).  The table starts on a
 // 16-byte boundary, so the flag that BATCH scenes keep in bit 0 of a link survives the addition.
-__device__ __forceinline__ void stage_nodes_in_lds(uint4* lds_nodes, const DNode32* nodes32, uint32_t n_nodes) {
+__device__ __forceinline__ void stage_nodes_in_lds(uint4* lds_nodes, const DNode32* nodes32, const uint32_t* leaf_codes, uint32_t n_nodes) {
     const uint4* src = reinterpret_cast<const uint4*>(nodes32);
     const uint32_t bias = lds_address(lds_nodes);
     for (uint32_t i = threadIdx.x; i < 2u * n_nodes; i += blockDim.x) {
         uint4 v = src[i];
-        if (i & 1u) v.z += bias;   // second half of a record: planes z, link, surface code
+        if (i & 1u) {   // second half of a record: planes z, the two links (NODE32_LEAF in the top bit of `down` is not touched: records lie below 2^30)
+            v.z += bias;
+            v.w += bias;
+        }
         lds_nodes[i] = v;
     }
+    uint32_t* codes = reinterpret_cast<uint32_t*>(lds_nodes + 2u * n_nodes);   // the leaf codes follow the records
+    for (uint32_t i = threadIdx.x; i < n_nodes; i += blockDim.x) codes[i] = leaf_codes[i];
 }
+// Where the tables that follow the tree start in LDS, in 16-byte units from the start of the node records
+__device__ __forceinline__ uint32_t lds_after_tree(uint32_t n_nodes) { return (uint32_t)(node_tables_lds_bytes(n_nodes) >> 4); }
 struct TraverseWork {
     const uint4* lds_nodes;     // LDS copy of the f32 node records (LDS_NODES)
     uint32_t lds_base;          // its LDS address: with LDS_NODES the walk's node positions are LDS addresses
@@ -644,20 +651,21 @@ __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& 
     uint32_t n_pending = 0;   // wave-uniform
     bool undecided = false;
     uint32_t at = have ? node : end;
-    while (at < end) {        // lanes leave the loop one by one; the wave stays until all have left
+    if (at < end) for (;;) {   // lanes leave the loop one by one (test at the bottom); the wave stays until all have left
         // the record: six planes (f32, or grid steps as f32), whether it is a leaf, its surface code if so,
         // and the byte offset of the record that follows its subtree
         float planes[6];
         bool is_leaf, contained = false;
-        uint32_t leaf_code, succ;
+        uint32_t succ, down;   // where the lane goes if the box is missed / hit (a leaf's `down` carries WAIT)
         if (REC16) {
             const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes16) + at);
             planes[0] = (float)(r.x & 0xFFFFu); planes[1] = (float)(r.x >> 16);
             planes[2] = (float)(r.y & 0xFFFFu); planes[3] = (float)(r.y >> 16);
             planes[4] = (float)(r.z & 0xFFFFu); planes[5] = (float)(r.z >> 16);
             is_leaf = r.w < NODE16_INTERNAL;
-            leaf_code = r.w;
+            leaf = r.w;   // only read once the lane waits on this leaf; a lane that walks on overwrites it
             succ = is_leaf ? at + 16u : r.w << 4;   // the tag bits shift out; a leaf is followed by the next record
+            down = is_leaf ? (succ | WAIT) : at + REC_BYTES;
         } else {
             uint4 n0, n1;
             if (LDS_NODES) {
@@ -670,8 +678,9 @@ __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& 
             }
             planes[0] = __uint_as_float(n0.x); planes[1] = __uint_as_float(n0.y); planes[2] = __uint_as_float(n0.z);
             planes[3] = __uint_as_float(n0.w); planes[4] = __uint_as_float(n1.x); planes[5] = __uint_as_float(n1.y);
-            is_leaf = n1.w != NONE;
-            leaf_code = n1.w;
+            static_assert(NODE32_LEAF == WAIT, "a leaf's `down` link is the waiting lane's state as it stands");
+            down = n1.w;
+            is_leaf = (int32_t)n1.w < 0;
             succ = BATCH ? (n1.z & ~15u) : n1.z;   // scenes of the BATCH form keep a flag in the (otherwise zero) low bits of a leaf's link
             contained = BATCH && (n1.z & 1u) != 0u;
         }
@@ -691,19 +700,19 @@ __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& 
         // combined flag costs two vector instructions per step): f32 says hit (that implies decided) on a leaf ...
         n_pending += (uint32_t)__popcll(ballot64(hit) & ballot64(is_leaf));
         if (batch_undecided) n_pending += (uint32_t)__popcll(ballot64(true) & ~ballot64(decided));   // ... or, where there are many, undecided
-        leaf = leaf_code;   // only read once the lane waits on this leaf; a lane that walks on overwrites it
-        const uint32_t down = is_leaf ? (succ | WAIT) : at + REC_BYTES;   // links are byte offsets; a leaf's successor is its miss link as well
         const uint32_t next = hit ? down : succ;
         at = decided ? next : (at | OPEN);
 #ifdef RTX_PROFILE_PHASES
         ++prof.iters;
 #endif
-        if (n_pending >= PEND_AT) break;   // wave-uniform
+        if (n_pending >= PEND_AT || at >= end) break;   // the first is wave-uniform
     }
+    uint32_t leaf_at = 0;   // f32 records: position of the leaf a waiting lane stands on (its surface code is read below)
     if (have) {
         pending = (at & WAIT) != 0u;
         undecided = (at & OPEN) != 0u;
         node = at & ~(WAIT | OPEN);
+        leaf_at = node - REC_BYTES;   // a waiting lane has moved on to the leaf's successor, the next record
     }
     // ---- phase 1b: the boxes left undecided, for all such lanes together
     if (undecided) {
@@ -721,8 +730,8 @@ __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& 
             uint4 n1;
             if (LDS_NODES) n1 = lds_read_u4(node, 1u);
             else n1 = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes32) + node)[1];
-            is_leaf = n1.w != NONE;
-            leaf_code = n1.w;
+            is_leaf = (int32_t)n1.w < 0;
+            leaf_code = leaf;
             succ = BATCH ? (n1.z & ~15u) : n1.z;
         }
         const double2* bp = reinterpret_cast<const double2*>(sc.boxes64 + ((node - (LDS_NODES ? w.lds_base : 0u)) >> REC_SHIFT));
@@ -730,9 +739,19 @@ __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& 
         if (COUNT) ++c_fallback;
         const bool hit = tier2_box(q0, q1, q2, o, d, tmin, tmax, scene_filter);
         pending = hit && is_leaf;
+        leaf_at = node;
         node = (hit && !is_leaf) ? node + REC_BYTES : succ;
         leaf = pending ? leaf_code : leaf;
         undecided = false;
+    }
+    if (!REC16 && pending) {   // the waiting lanes' surface codes, by node index
+        const uint32_t i = (leaf_at - (LDS_NODES ? w.lds_base : 0u)) >> REC_SHIFT;
+        if (LDS_NODES) {
+            typedef __attribute__((address_space(3))) const uint32_t* lds_u32_ptr;
+            leaf = ((lds_u32_ptr)(uintptr_t)end)[i];   // the codes follow the records: `end` is the LDS address behind the last one
+        } else {
+            leaf = sc.leaf_codes[i];
+        }
     }
     PT(p1);
 
@@ -889,12 +908,12 @@ __global__ __launch_bounds__(LDS_NODES ? TRAVERSE_LDS_BLOCK : BLOCK) void k_trav
                                                                                        uint32_t lds_surfaces) {
     // LDS_NODES: the f32 node records of the whole tree, then (lds_surfaces) the sphere and planar tables
     extern __shared__ uint4 lds_nodes[];
-    const uint4* lds_spheres = lds_nodes + 2u * sc.n_nodes;
+    const uint4* lds_spheres = lds_nodes + lds_after_tree(sc.n_nodes);
     const uint4* lds_planars = lds_spheres + 2u * sc.n_spheres;
     if (LDS_NODES) {
-        stage_nodes_in_lds(lds_nodes, sc.nodes32, sc.n_nodes);
+        stage_nodes_in_lds(lds_nodes, sc.nodes32, sc.leaf_codes, sc.n_nodes);
         if (lds_surfaces) {
-            uint4* dst_s = lds_nodes + 2u * sc.n_nodes;
+            uint4* dst_s = lds_nodes + lds_after_tree(sc.n_nodes);
             const uint4* src_s = reinterpret_cast<const uint4*>(sc.spheres);
             for (uint32_t i = threadIdx.x; i < 2u * sc.n_spheres; i += blockDim.x) dst_s[i] = src_s[i];
             uint4* dst_p = dst_s + 2u * sc.n_spheres;
@@ -1423,7 +1442,7 @@ __device__ __forceinline__ DHits uniform_hits(const DHits& h) {
 __device__ __forceinline__ DScene uniform_scene(const DScene& s) {
     DScene u = s;
     u.nodes = uniform_p(s.nodes); u.spheres = uniform_p(s.spheres); u.planars = uniform_p(s.planars);
-    u.nodes32 = uniform_p(s.nodes32);
+    u.nodes32 = uniform_p(s.nodes32); u.leaf_codes = uniform_p(s.leaf_codes);
     u.nodes16 = uniform_p(s.nodes16);
     u.boxes64 = uniform_p(s.boxes64); u.shade_recs = uniform_p(s.shade_recs); u.rec_user_id = uniform_p(s.rec_user_id);
     u.n_nodes = uniform32(s.n_nodes); u.filter_ok = uniform32(s.filter_ok); u.batch_undecided = uniform32(s.batch_undecided); u.pend_at = uniform32(s.pend_at); u.refill_at = uniform32(s.refill_at); u.bounce_at = uniform32(s.bounce_at);
@@ -1446,7 +1465,7 @@ __device__ RTX_PHASE_INLINE void phase_traverse(const DRenderParams* pp, uint32_
     TraverseWork w{};
     w.lds_nodes = lds_nodes;
     w.lds_base = uniform32(lds_address(lds_nodes));
-    w.lds_spheres = lds_nodes + 2u * P->sc.n_nodes;
+    w.lds_spheres = lds_nodes + lds_after_tree(P->sc.n_nodes);
     w.lds_planars = w.lds_spheres + 2u * P->sc.n_spheres;
     w.lds_surfaces = P->lds_surfaces;
     w.base = uniform32(base);
@@ -1473,7 +1492,7 @@ __device__ RTX_PHASE_INLINE uint32_t phase_shade(const DRenderParams* pp, uint32
     // last-level cache and the scalar registers that hold table pointers (+1.5 % on the frame).
     const DState st = uniform_state(P->st[parity]);
     extern __shared__ uint4 lds_nodes[];
-    const uint4* lds_recs = uniform32(P->lds_recs) ? lds_nodes + 2u * P->sc.n_nodes + 2u * P->sc.n_spheres + 8u * P->sc.n_planars : nullptr;
+    const uint4* lds_recs = uniform32(P->lds_recs) ? lds_nodes + lds_after_tree(P->sc.n_nodes) + 2u * P->sc.n_spheres + 8u * P->sc.n_planars : nullptr;
     return shade_wave<DEEP>(uniform_scene(P->sc), P->cam, st, uniform_hits(P->hits), base, count, st, uniform64(P->seed), uniform_p(P->accum), lds_recs);
 }
 
@@ -1495,10 +1514,10 @@ __device__ RTX_PHASE_INLINE unsigned long long phase_tail(const DRenderParams* p
     TraverseWork w{};
     w.lds_nodes = lds_nodes;
     w.lds_base = uniform32(lds_address(lds_nodes));
-    w.lds_spheres = lds_nodes + 2u * sc.n_nodes;
+    w.lds_spheres = lds_nodes + lds_after_tree(sc.n_nodes);
     w.lds_planars = w.lds_spheres + 2u * sc.n_spheres;
     w.lds_surfaces = uniform32(P->lds_surfaces);
-    const uint4* lds_recs = (LDS_NODES && uniform32(P->lds_recs)) ? lds_nodes + 2u * sc.n_nodes + 2u * sc.n_spheres + 8u * sc.n_planars : nullptr;
+    const uint4* lds_recs = (LDS_NODES && uniform32(P->lds_recs)) ? lds_nodes + lds_after_tree(sc.n_nodes) + 2u * sc.n_spheres + 8u * sc.n_planars : nullptr;
     const double tmin = uniform_f64(P->tmin), tmax0 = uniform_f64(P->tmax0);
     const uint64_t seed = uniform64(P->seed);
     const uint32_t max_depth = uniform32(P->cam.max_depth);
@@ -1561,9 +1580,9 @@ __device__ RTX_PHASE_INLINE unsigned long long phase_tail(const DRenderParams* p
 __device__ __forceinline__ void stage_scene_in_lds(const DRenderParams* P) {
     extern __shared__ uint4 lds_nodes[];
     const DScene& sc = P->sc;
-    stage_nodes_in_lds(lds_nodes, sc.nodes32, sc.n_nodes);
+    stage_nodes_in_lds(lds_nodes, sc.nodes32, sc.leaf_codes, sc.n_nodes);
     if (P->lds_surfaces) {
-        uint4* dst_s = lds_nodes + 2u * sc.n_nodes;
+        uint4* dst_s = lds_nodes + lds_after_tree(sc.n_nodes);
         const uint4* src_s = reinterpret_cast<const uint4*>(sc.spheres);
         for (uint32_t i = threadIdx.x; i < 2u * sc.n_spheres; i += blockDim.x) dst_s[i] = src_s[i];
         uint4* dst_p = dst_s + 2u * sc.n_spheres;
@@ -1700,11 +1719,11 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
     const V3 background = v3(uniform_f64(P->cam.background[0]), uniform_f64(P->cam.background[1]), uniform_f64(P->cam.background[2]));
     const double tmin = uniform_f64(P->tmin), tmax0 = uniform_f64(P->tmax0);
     double* const accum = uniform_p(P->accum);
-    const uint4* lds_recs = lds_nodes + 2u * sc.n_nodes + 2u * sc.n_spheres + 8u * sc.n_planars;
+    const uint4* lds_recs = lds_nodes + lds_after_tree(sc.n_nodes) + 2u * sc.n_spheres + 8u * sc.n_planars;
     TraverseWork w{};
     w.lds_nodes = lds_nodes;
     w.lds_base = uniform32(lds_address(lds_nodes));
-    w.lds_spheres = lds_nodes + 2u * sc.n_nodes;
+    w.lds_spheres = lds_nodes + lds_after_tree(sc.n_nodes);
     w.lds_planars = w.lds_spheres + 2u * sc.n_spheres;
     w.lds_surfaces = 1u;
     const uint32_t root = w.lds_base, end = root + sc.n_nodes * 32u;   // node positions are LDS addresses
@@ -1908,7 +1927,7 @@ void launch_traverse_f32(const DScene& sc, const DState& rays, const DHits& hits
     if (lds_mode) {
         const uint32_t waves_per_block = TRAVERSE_LDS_BLOCK / 64;
         dim3 g((pool.n_sub + waves_per_block - 1) / waves_per_block), b(TRAVERSE_LDS_BLOCK);
-        size_t lds = (size_t)sc.n_nodes * sizeof(DNode32);
+        size_t lds = node_tables_lds_bytes(sc.n_nodes);
         const uint32_t surf = lds_mode == 2u ? 1u : 0u;
         if (surf) lds += (size_t)sc.n_spheres * sizeof(DSphere) + (size_t)sc.n_planars * sizeof(DPlanar);
 #ifdef RTX_PROFILE_PHASES
@@ -1947,7 +1966,7 @@ void launch_shade(const DScene& sc, const DCamera& cam, const DState& cur, const
 }
 // lds_mode: 0 tree in global memory; 1 tree in LDS; 2 tree and surface tables in LDS; 3 and 4: modes 2 and 1 in the WIDE form of the kernel
 size_t persistent_lds_bytes(const DScene& sc, uint32_t lds_mode, bool recs) {
-    size_t lds = lds_mode ? (size_t)sc.n_nodes * sizeof(DNode32) : 0;
+    size_t lds = lds_mode ? node_tables_lds_bytes(sc.n_nodes) : 0;
     if (lds_mode == 2u || lds_mode == 3u) {
         lds += (size_t)sc.n_spheres * sizeof(DSphere) + (size_t)sc.n_planars * sizeof(DPlanar);
         if (recs) lds += ((size_t)sc.n_spheres + sc.n_planars) * sizeof(DShadeRec);
