@@ -43,7 +43,19 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 SEED, SCENE_SEED = 0xC0FFEE, 0xC0FFEE
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (spec)
 FP64_VECTOR_PEAK_TF = 78.6   # MI355X vector FP64 peak (spec), 2 flop per FMA lane
-KERNEL = "k_render_persistent"
+KERNEL = "k_render_persistent"     # the single launch with its paths in a pool ...
+KERNEL_RESIDENT = "k_render_resident"   # ... or in registers (scenes that sit in LDS whole, from a scene's second call on, where paths bounce)
+
+
+def frame_kernel(names):
+    """Of the kernel names of a profile, the one that rendered the timed frames: the resident form if it ran at all (a scene's
+    first call takes the pooled form), else the pooled form's non-counting instance."""
+    names = list(names)
+    for want in (KERNEL_RESIDENT, KERNEL + "<false"):
+        hit = [k for k in names if k.replace("void ", "").replace("rtx::", "").startswith(want)]
+        if hit:
+            return hit[0]
+    return None
 
 # name -> (scene function kwargs -> (surfaces, camera), nominal spp, spp run by default, BVH built on: "host" | "device")
 # The 10^6-surface frames take minutes at their nominal 1000 spp: they run at 20 spp unless --spp says otherwise
@@ -150,9 +162,9 @@ def committed_traffic(name):
             rec = doc.get("configs", {}).get(name)
             return (rec["hbm_bytes_per_launch"], rec["rays_per_launch"], "profiles/hbm_traffic.json (committed): " + rec.get("source", "")) if rec else (None, None, None)
         recs = doc["kernels"]
-        k = max((k for k in recs if k.split("<")[0] == KERNEL), key=lambda k: (not k.startswith(KERNEL + "<true"), recs[k]["launches"]))
+        k = frame_kernel(recs)
         return recs[k]["hbm_bytes_per_launch"], recs[k].get("rays_per_launch"), "profiles/hbm_traffic.json (committed): " + recs[k].get("source", "")
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, TypeError):
         return None, None, None
 
 
@@ -167,7 +179,7 @@ def committed_valu_issue(name):
     try:
         with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) as fh:
             ks = json.load(fh)["kernels"]
-        r = ks[next(k for k in ks if k.startswith(KERNEL + "<false"))]
+        r = ks[frame_kernel(ks)]
         simd_cycles = 1024.0 * r["GRBM_GUI_ACTIVE"] / 8.0   # the counter is summed over the eight XCDs
         f64 = r["SQ_INSTS_VALU_ADD_F64"] + r["SQ_INSTS_VALU_FMA_F64"] + r["SQ_INSTS_VALU_MUL_F64"]
         slow = f64 + r["SQ_INSTS_VALU_INT64"] + r["SQ_INSTS_VALU_CVT"]
@@ -176,7 +188,7 @@ def committed_valu_issue(name):
                 "frac_if_every_instruction_took_4_cycles": round(4.0 * r["SQ_INSTS_VALU"] / simd_cycles, 3),
                 "lanes_active": round(r["SQ_THREAD_CYCLES_VALU"] / (r["SQ_ACTIVE_INST_VALU"] * 64.0), 3),
                 "source": "profiles/r02_pmc_summary.json (committed, not of this run), issue costs from profiles/r01_valu_rate.txt"}
-    except (OSError, KeyError, ValueError, StopIteration, ZeroDivisionError):
+    except (OSError, KeyError, ValueError, StopIteration, ZeroDivisionError, TypeError):
         return None
 
 
@@ -191,8 +203,9 @@ def live_traffic(args):
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
+    # one warm-up frame as in the timed run: a scene's first call always takes the pooled form of the kernel
     child = ["python3", os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", args.config, "--spp", str(args.spp), "--width", str(args.width),
-             "--steps", "1", "--warmup", "0"]
+             "--steps", "1", "--warmup", "1"]
     got, rays = {}, None
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -204,18 +217,21 @@ def live_traffic(args):
             for line in r.stdout.splitlines():
                 if line.startswith("{"):
                     rays = json.loads(line)["config"]["rays_per_frame"]
-            total, launches = 0.0, set()
+            per_kernel = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if KERNEL in row["Kernel_Name"] and row["Counter_Name"] == ctr:
-                            total += float(row["Counter_Value"])
-                            launches.add(row["Dispatch_Id"])
-            if not launches:
-                return None, None, f"no {KERNEL} dispatch in the {ctr} pass"
-            got[ctr] = total * 1024.0 / len(launches)
+                        if row["Counter_Name"] == ctr:
+                            tot = per_kernel.setdefault(row["Kernel_Name"], [0.0, set()])
+                            tot[0] += float(row["Counter_Value"])
+                            tot[1].add(row["Dispatch_Id"])
+            k = frame_kernel(per_kernel)
+            if k is None:
+                return None, None, f"no {KERNEL} / {KERNEL_RESIDENT} dispatch in the {ctr} pass"
+            kernel_seen = k.replace("void ", "").replace("rtx::", "").split("(")[0]
+            got[ctr] = per_kernel[k][0] * 1024.0 / len(per_kernel[k][1])
         return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], rays, (
-            "live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one pass each) over `python3 bench.py --pmc-child` on this box; "
+            f"live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one pass each) of {kernel_seen} over `python3 bench.py --pmc-child` on this box; "
             f"read {2.0 * got['FETCH_SIZE'] / 1e9:.1f} GB (FETCH_SIZE x 2) + written {got['WRITE_SIZE'] / 1e9:.1f} GB")
     except (OSError, ValueError, KeyError) as e:
         return None, None, f"live PMC passes failed: {e}"
@@ -464,7 +480,7 @@ def roofline(rt, scene, n_nodes, icam, stats, begin, count, acc, stream, args):
         "measured_over_algorithmic": round(traffic / rays_per_launch / (state_bytes_per_ray if tree_on_chip else scene_bytes_per_ray + state_bytes_per_ray), 3) if traffic else None,
     }
     common = {
-        "kernel": KERNEL,
+        "kernel": KERNEL_RESIDENT if KERNEL_RESIDENT in (src or "") else KERNEL,
         "traffic": round(traffic, 1) if traffic else None,
         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE)",
         "traffic_source": src,
@@ -482,7 +498,9 @@ def roofline(rt, scene, n_nodes, icam, stats, begin, count, acc, stream, args):
         "valu_issue": committed_valu_issue(args.config),
         "on_chip_note": f"{scene_bytes_per_ray:.0f} B/ray of the byte formula are node and surface records "
                         + ("served from LDS (the tree and the surface tables are copied there once per block): not HBM traffic"
-                           if tree_on_chip else "read from global memory (the tree is far larger than LDS and L2)"),
+                           if tree_on_chip else "read from global memory (the tree is far larger than LDS and L2)")
+                        + ("; in the resident form of the kernel the paths stay in registers from bounce to bounce, so the formula's ray state and hit "
+                           "records do not move either: what is measured is the image's atomic adds" if KERNEL_RESIDENT in (src or "") else ""),
     }
     if tree_on_chip:
         return dict({"bound": "valu_f64", "achieved": round(tf, 3), "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",

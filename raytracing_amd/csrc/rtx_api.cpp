@@ -435,8 +435,9 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     sc->d.refill_at = env_u32("RTX_REFILL_AT", planar_scene && small_scene ? 16u : 32u);
     if (sc->d.refill_at > 64u) sc->d.refill_at = 64u;
     // The kernel that keeps the paths in registers runs a bounce (some 1500 instructions whatever the number of lanes in it) once this
-    // many lanes are due: 16 / 24 / 32 / 40 / 48 / 56 / 64 give 51.8 / 45.2 / 42.5 / 40.7 / 40.3 / 40.4 / 44.9 ms per 100 spp of the headline frame.
-    sc->d.bounce_at = env_u32("RTX_BOUNCE_AT", 48u);
+    // many lanes are due: 16 / 24 / 32 / 40 / 48 / 56 / 64 give 51.8 / 45.2 / 42.5 / 40.7 / 40.3 / 40.4 / 44.9 ms per 100 spp of the headline frame
+    // (measured again after the walk's last trims: 44 / 48 / 52 give 69.7 / 69.3 / 69.1 ms per 200 spp).
+    sc->d.bounce_at = env_u32("RTX_BOUNCE_AT", 52u);
     if (sc->d.bounce_at > 64u) sc->d.bounce_at = 64u;
     sc->d.nodes32 = sc->nodes32.p;
     sc->d.leaf_codes = sc->leaf_codes.p;
@@ -621,11 +622,15 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         }
         if (mode == 2u) lds_recs = persistent_lds_bytes(sc->d, 2u, true) <= env_u32("RTX_LDS_SCENE_BYTES", 32u * 1024u);
         if (env_u32("RTX_LDS_RECS", 1, true) == 0u) lds_recs = false;
-        // Scenes that sit in LDS whole (tree, surface tables and shade records) take the resident form: paths stay in registers from
-        // bounce to bounce, the pool below holds nothing (RTX_RESIDENT=0 keeps the pooled form; the work counters exist there only).
-        const uint32_t resident_waves = (mode == 3u && lds_recs && !(flags & RTX_FLAG_COUNT_WORK) && env_u32("RTX_RESIDENT", 0, true) != 0u)
-                                            ? resident_waves_per_cu(sc->d)
-                                            : 0u;
+        // Scenes that sit in LDS whole (tree, surface tables and shade records) can take the resident form: paths stay in registers
+        // from bounce to bounce and the pool below holds nothing.  It is the faster form where paths bounce (the headline frame:
+        // 171.7 against 177.3 ms, a 62-spp call 22.1 against 23.2 ms) and the slower one where nearly every path ends at its first
+        // ray (a sparse soup in front of the sky: 2.6 against 2.2 ms for a 16-spp call), so the scene's last call decides: 1.5 rays
+        // per path or more.  A scene's first call, calls that count work (the counters exist in the pooled form only) and
+        // RTX_RESIDENT=0 take the pooled form; RTX_RESIDENT=1 forces the resident one.
+        const char* force_form = std::getenv("RTX_RESIDENT");
+        const bool want_resident = (force_form && *force_form) ? std::atoi(force_form) != 0 : sc->rays_per_path >= 1.5;
+        const uint32_t resident_waves = (mode == 3u && lds_recs && !(flags & RTX_FLAG_COUNT_WORK) && want_resident) ? resident_waves_per_cu(sc->d) : 0u;
         const bool resident = resident_waves != 0u;
         const uint32_t waves = sc->n_cus * (resident ? resident_waves : persistent_waves_per_cu(sc->d, mode, lds_recs));   // exactly what is resident at once
         const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 22);   // ~800 slots per wave: a round ends with a drain, so long rounds pay, but state that stays in the last-level cache pays too
@@ -676,13 +681,14 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         HIP_TRY(hipEventRecord(sc->ev1, s));
         if (no_wait) return RTX_OK;
         HIP_TRY(hipStreamSynchronize(s));
+        DRenderCtl back;
+        HIP_TRY(hipMemcpy(&back, pp->ctl.p, sizeof(back), hipMemcpyDeviceToHost));
+        if (total && !(flags & RTX_FLAG_COUNT_WORK)) sc->rays_per_path = (double)back.rays / (double)total;
         if (stats) {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, sc->ev0, sc->ev1);
             stats->ms_total = ms;
             stats->paths = total;
-            DRenderCtl back;
-            HIP_TRY(hipMemcpy(&back, pp->ctl.p, sizeof(back), hipMemcpyDeviceToHost));
             stats->rays = back.rays;
             stats->node_visits = back.node_visits;
             stats->sphere_tests = back.sphere_tests;

@@ -113,6 +113,7 @@ struct rtx_scene {
     rtx::DevBuf<uint32_t> rec_user_id;
     rtx::DevBuf<rtx::DShadeRec> shade_recs;
     bool f32_ok = false;   // every box plane is small enough for the single-precision tier
+    double rays_per_path = 0.0;   // of the scene's last render call that was waited for (0: none yet); picks the form of the next one
     // Lanes of the render loop, created on first use and kept.  Lane 0 also serves rtx_trace_closest.
     std::vector<std::unique_ptr<rtx::PathPool>> lanes;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -27,6 +27,6 @@ cat "$OUT/bench_under_rocprof.json"
 find "$OUT/stats" -name '*kernel_trace.csv' -delete
 find "$OUT/stats" -name '*kernel_stats.csv' -exec head -12 {} \;
 echo "== pmc"
-timeout -k 10 1000 python3 tools/pmc_profile.py "$OUT/pmc" --steps 1 --warmup 0 --no-cpu-baseline --no-pmc > "$OUT/pmc.log" 2>&1
+timeout -k 10 1000 python3 tools/pmc_profile.py "$OUT/pmc" --steps 1 --warmup 1 --no-cpu-baseline --no-pmc > "$OUT/pmc.log" 2>&1
 tail -30 "$OUT/pmc.log"
 find "$OUT/pmc" -name '*counter_collection.csv' -delete
