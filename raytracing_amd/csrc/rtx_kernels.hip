@@ -579,6 +579,21 @@ __device__ __forceinline__ uint4 lds_read_u4(uint32_t lds_addr, uint32_t index) 
 __device__ __forceinline__ uint32_t lds_address(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
+typedef __attribute__((address_space(3))) u32x4* lds_u4_wptr;
+__device__ __forceinline__ void lds_write_u4(uint32_t lds_addr, uint32_t index, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+    u32x4 v;
+    v.x = x; v.y = y; v.z = z; v.w = w;
+    ((lds_u4_wptr)(uintptr_t)lds_addr)[index] = v;
+}
+__device__ __forceinline__ void lds_write_d2(uint32_t lds_addr, uint32_t index, double a, double b) {
+    lds_write_u4(lds_addr, index, (uint32_t)__double2loint(a), (uint32_t)__double2hiint(a), (uint32_t)__double2loint(b), (uint32_t)__double2hiint(b));
+}
+__device__ __forceinline__ void lds_read_d2(uint32_t lds_addr, uint32_t index, double& a, double& b) {
+    const uint4 v = lds_read_u4(lds_addr, index);
+    a = __hiloint2double((int)v.y, (int)v.x);
+    b = __hiloint2double((int)v.w, (int)v.z);
+}
+constexpr uint32_t RESIDENT_STAGE_BYTES = 64u;   // a staged primary ray of the resident render kernel: origin, direction (6 f64), pixel, sample, draw count (+ pad)
 // Copies the f32 node records into LDS.  In the copy a record's link (byte offset of its successor in the table) becomes
 // the successor's LDS address: the walk then keeps LDS addresses, not offsets, and the address of a visit's two reads is
 // the lane's state itself instead of table + offset (one vector instruction of a visit's thirty).  The table starts on a
@@ -1727,6 +1742,9 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
     w.lds_planars = w.lds_spheres + 2u * sc.n_spheres;
     w.lds_surfaces = 1u;
     const uint32_t root = w.lds_base, end = root + sc.n_nodes * 32u;   // node positions are LDS addresses
+    // This wave's 64 staged primary rays (RESIDENT_STAGE_BYTES each) lie behind the scene's tables
+    const uint32_t stage_lds = lds_address(lds_recs + 4u * (sc.n_spheres + sc.n_planars)) + uniform32(threadIdx.x >> 6) * (64u * RESIDENT_STAGE_BYTES);
+    uint32_t st_head = 0, st_cnt = 0;   // entries [st_head, st_cnt) are staged and not yet taken (wave-uniform)
     const uint32_t PEND_AT = sc.pend_at, BOUNCE_AT = sc.bounce_at;
     const bool scene_filter = sc.filter_ok != 0u;
 
@@ -1779,51 +1797,74 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
                 }
             }
             // ---- the next paths of the call for the lanes without one
+            // Primary rays are made 64 at a time, by the whole wave, and staged in LDS; a lane whose path has ended takes the next
+            // staged one (four LDS reads).  Made on demand they cost their ~400 instructions (path index, sample_square, the defocus
+            // disk's rejection loop, get_ray) for the third of a wave whose paths ended at this bounce.
             if (!exhausted) {
-                const unsigned long long vacant = ballot64(!have);
-                const uint32_t need = (uint32_t)__popcll(vacant);
-                if (need) {
-                    // The wave draws path indices from the call's counter a chunk at a time (one returning atomic on a single word
-                    // per bounce of every wave would be the whole chip's atomic rate several times over) and hands them out from
-                    // the chunk; chunks shrink towards the end of the call so that no wave is left with a long tail of its own.
-                    if (chunk_next == chunk_end && !drained) {
-                        unsigned long long want = left_estimate / ((unsigned long long)n_waves * 8ull);
-                        want = want < 64ull ? 64ull : want > 4096ull ? 4096ull : want;
-                        unsigned long long first = 0;
-                        if (lane == 0) first = atomicAdd(&ctl->next_path[0], want);
-                        first = uniform64(first);
-                        if (first >= total) {
-                            drained = true;
-                        } else {
-                            const unsigned long long rest = total - first;
-                            chunk_next = first;
-                            chunk_end = first + (rest < want ? rest : want);
-                            drained = rest <= want;
-                            left_estimate = rest;
+                unsigned long long vacant = ballot64(!have);
+                uint32_t need = (uint32_t)__popcll(vacant);
+                for (uint32_t pass = 0; pass < 2u && need != 0u; ++pass) {
+                    if (st_head == st_cnt) {   // stage the wave's next 64 paths
+                        // The wave draws path indices from the call's counter a chunk at a time (one returning atomic on a single word
+                        // per bounce of every wave would be the whole chip's atomic rate several times over); chunks shrink towards the
+                        // end of the call so that no wave is left with a long tail of its own.
+                        if (chunk_next == chunk_end && !drained) {
+                            unsigned long long want = left_estimate / ((unsigned long long)n_waves * 8ull);
+                            want = want < 64ull ? 64ull : want > 4096ull ? 4096ull : want;
+                            unsigned long long first = 0;
+                            if (lane == 0) first = atomicAdd(&ctl->next_path[0], want);
+                            first = uniform64(first);
+                            if (first >= total) {
+                                drained = true;
+                            } else {
+                                const unsigned long long rest = total - first;
+                                chunk_next = first;
+                                chunk_end = first + (rest < want ? rest : want);
+                                drained = rest <= want;
+                                left_estimate = rest;
+                            }
                         }
-                    }
-                    const unsigned long long in_chunk = chunk_end - chunk_next;
-                    const uint32_t got = in_chunk < need ? (uint32_t)in_chunk : need;
-                    const unsigned long long first = chunk_next;
-                    chunk_next += got;
-                    exhausted = drained && chunk_next == chunk_end;
-                    if (got) {   // wave-uniform
-                        const uint32_t r = rank_below(vacant, lane);
-                        const bool takes = !have && r < got;
+                        const unsigned long long in_chunk = chunk_end - chunk_next;
+                        const uint32_t got = in_chunk < 64ull ? (uint32_t)in_chunk : 64u;
+                        if (got == 0u) break;   // nothing left for this wave
+                        const unsigned long long first = chunk_next;
+                        chunk_next += got;
+                        const bool makes = lane < got;
                         uint32_t new_pixel, sample_off;
-                        split_path_index<false>(first + (takes ? r : 0u), npix, new_pixel, sample_off);
+                        split_path_index<false>(first + (makes ? lane : 0u), npix, new_pixel, sample_off);
                         const uint32_t new_sample = spp_begin + sample_off;
                         V3 no, nd;
                         uint32_t new_draw;
-                        start_path_wave(cam, seed, takes, new_pixel, new_sample, no, nd, new_draw);
-                        if (takes) {
-                            o = no; d = nd; beta = v3(1.0, 1.0, 1.0);
-                            pixel = new_pixel; sample = new_sample; draw = new_draw; depth = 0u;
-                            have = true;
-                            fresh = true;
+                        start_path_wave(cam, seed, makes, new_pixel, new_sample, no, nd, new_draw);
+                        if (makes) {
+                            const uint32_t entry = stage_lds + lane * RESIDENT_STAGE_BYTES;
+                            lds_write_d2(entry, 0u, no.x, no.y);
+                            lds_write_d2(entry, 1u, no.z, nd.x);
+                            lds_write_d2(entry, 2u, nd.y, nd.z);
+                            lds_write_u4(entry, 3u, new_pixel, new_sample, new_draw, 0u);
                         }
+                        st_head = 0u;
+                        st_cnt = got;
                     }
+                    const uint32_t avail = st_cnt - st_head;
+                    const uint32_t take = need < avail ? need : avail;
+                    const uint32_t r = rank_below(vacant, lane);
+                    if (!have && r < take) {
+                        const uint32_t entry = stage_lds + (st_head + r) * RESIDENT_STAGE_BYTES;
+                        lds_read_d2(entry, 0u, o.x, o.y);
+                        lds_read_d2(entry, 1u, o.z, d.x);
+                        lds_read_d2(entry, 2u, d.y, d.z);
+                        const uint4 ids = lds_read_u4(entry, 3u);
+                        pixel = ids.x; sample = ids.y; draw = ids.z; depth = 0u;
+                        beta = v3(1.0, 1.0, 1.0);
+                        have = true;
+                        fresh = true;
+                    }
+                    st_head += take;
+                    vacant = ballot64(!have);
+                    need = (uint32_t)__popcll(vacant);
                 }
+                exhausted = drained && chunk_next == chunk_end && st_head == st_cnt;
             }
             if (fresh) {
                 tmax = tmax0;
@@ -2015,16 +2056,18 @@ void launch_render_persistent(const DRenderParams* params, const DRenderParams& 
 }
 // The resident form (k_render_resident): one 1024-thread block per CU like the WIDE form, for scenes it can take (see
 // resident_form_fits); 0 if the kernel cannot be resident with that much LDS.
+// LDS of the resident form: the scene's tables and, per wave, 64 staged primary rays
+static size_t resident_lds_bytes(const DScene& sc) { return persistent_lds_bytes(sc, 3u, true) + (size_t)(WIDE_BLOCK / 64u) * 64u * RESIDENT_STAGE_BYTES; }
 uint32_t resident_waves_per_cu(const DScene& sc) {
     int nb = 0;
-    const size_t lds = persistent_lds_bytes(sc, 3u, true);
+    const size_t lds = resident_lds_bytes(sc);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_resident<false>, WIDE_BLOCK, lds) != hipSuccess || nb < 1) return 0u;
     return (uint32_t)nb * (WIDE_BLOCK / 64);
 }
 void launch_render_resident(const DRenderParams* params, const DRenderParams& host_params, hipStream_t s) {
     const uint32_t block_waves = WIDE_BLOCK / 64;
     dim3 g((host_params.n_sub + block_waves - 1) / block_waves), b(WIDE_BLOCK);
-    const size_t lds = persistent_lds_bytes(host_params.sc, 3u, true);
+    const size_t lds = resident_lds_bytes(host_params.sc);
     if (host_params.sc.batch_undecided != 0u) hipLaunchKernelGGL((k_render_resident<true>), g, b, lds, s, params);
     else hipLaunchKernelGGL((k_render_resident<false>), g, b, lds, s, params);
 }
