@@ -630,7 +630,14 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         // RTX_RESIDENT=0 take the pooled form; RTX_RESIDENT=1 forces the resident one.
         const char* force_form = std::getenv("RTX_RESIDENT");
         const bool want_resident = (force_form && *force_form) ? std::atoi(force_form) != 0 : sc->rays_per_path >= 1.5;
-        const uint32_t resident_waves = (mode == 3u && lds_recs && !(flags & RTX_FLAG_COUNT_WORK) && want_resident) ? resident_waves_per_cu(sc->d) : 0u;
+        // (its waves stage the primary rays they make in LDS, 64 at a time where there is room, else 48, 32 or 16)
+        uint32_t resident_waves = 0u, resident_batch = 0u;
+        if (mode == 3u && lds_recs && !(flags & RTX_FLAG_COUNT_WORK) && want_resident)
+            for (uint32_t b : {64u, 48u, 32u, 16u}) {
+                resident_waves = resident_waves_per_cu(sc->d, b);
+                resident_batch = b;
+                if (resident_waves) break;
+            }
         const bool resident = resident_waves != 0u;
         const uint32_t waves = sc->n_cus * (resident ? resident_waves : persistent_waves_per_cu(sc->d, mode, lds_recs));   // exactly what is resident at once
         const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 22);   // ~800 slots per wave: a round ends with a drain, so long rounds pay, but state that stays in the last-level cache pays too
@@ -665,6 +672,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         P.spp_begin = spp_begin;
         P.lds_surfaces = (mode == 2u || mode == 3u) ? 1u : 0u;
         P.lds_recs = lds_recs ? 1u : 0u;
+        P.resident_batch = resident_batch;
         P.tail_in_registers = env_u32("RTX_TAIL_IN_REGISTERS", 1, true);
         // block-by-block pixel order for trees that are walked from global memory (mode 0)
         P.tile_order = (cam->image_width % 32u == 0u && cam->image_height % 16u == 0u && !resident && env_u32("RTX_TILE_ORDER", mode == 0u ? 1u : 0u, true) != 0u) ? 1u : 0u;

@@ -205,7 +205,7 @@ struct DRenderParams {
     uint32_t lds_recs;      // the shade records are in LDS as well (behind the surface tables)
     uint32_t tile_order;    // path indices name pixels block by block (tiled_pixel) instead of row by row
     uint32_t tail_in_registers;   // the last row of rays of a wave finishes in registers (phase_tail)
-    uint32_t pad_[1];
+    uint32_t resident_batch;      // resident form: primary rays a wave makes and stages at a time (64, or fewer where LDS is short)
 };
 
 // ---------------------------------------------------------------- Vector3 (src/vector.rs)

@@ -23,7 +23,7 @@ size_t persistent_lds_bytes(const DScene& sc, uint32_t lds_mode, bool recs);
 uint32_t persistent_waves_per_cu(const DScene& sc, uint32_t lds_mode, bool recs);
 void launch_render_persistent(const DRenderParams* params, const DRenderParams& host_params, bool count_work, uint32_t lds_mode, hipStream_t s);
 // The same with every path resident in registers (scenes whose tree, surface tables and shade records fit one LDS copy per CU)
-uint32_t resident_waves_per_cu(const DScene& sc);   // 0: the kernel cannot be resident with that scene
+uint32_t resident_waves_per_cu(const DScene& sc, uint32_t batch);   // 0: the kernel cannot be resident with that scene
 void launch_render_resident(const DRenderParams* params, const DRenderParams& host_params, hipStream_t s);
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s);
 void launch_quantize(const double* in, uint64_t n, uint8_t* out, hipStream_t s);

@@ -1742,8 +1742,9 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
     w.lds_planars = w.lds_spheres + 2u * sc.n_spheres;
     w.lds_surfaces = 1u;
     const uint32_t root = w.lds_base, end = root + sc.n_nodes * 32u;   // node positions are LDS addresses
-    // This wave's 64 staged primary rays (RESIDENT_STAGE_BYTES each) lie behind the scene's tables
-    const uint32_t stage_lds = lds_address(lds_recs + 4u * (sc.n_spheres + sc.n_planars)) + uniform32(threadIdx.x >> 6) * (64u * RESIDENT_STAGE_BYTES);
+    // This wave's staged primary rays (`batch` of them, RESIDENT_STAGE_BYTES each) lie behind the scene's tables
+    const uint32_t batch = uniform32(P->resident_batch);
+    const uint32_t stage_lds = lds_address(lds_recs + 4u * (sc.n_spheres + sc.n_planars)) + uniform32(threadIdx.x >> 6) * (batch * RESIDENT_STAGE_BYTES);
     uint32_t st_head = 0, st_cnt = 0;   // entries [st_head, st_cnt) are staged and not yet taken (wave-uniform)
     const uint32_t PEND_AT = sc.pend_at, BOUNCE_AT = sc.bounce_at;
     const bool scene_filter = sc.filter_ok != 0u;
@@ -1797,14 +1798,14 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
                 }
             }
             // ---- the next paths of the call for the lanes without one
-            // Primary rays are made 64 at a time, by the whole wave, and staged in LDS; a lane whose path has ended takes the next
+            // Primary rays are made 64 at a time (fewer where LDS is short), by the whole wave, and staged in LDS; a lane whose path has ended takes the next
             // staged one (four LDS reads).  Made on demand they cost their ~400 instructions (path index, sample_square, the defocus
             // disk's rejection loop, get_ray) for the third of a wave whose paths ended at this bounce.
             if (!exhausted) {
                 unsigned long long vacant = ballot64(!have);
                 uint32_t need = (uint32_t)__popcll(vacant);
-                for (uint32_t pass = 0; pass < 2u && need != 0u; ++pass) {
-                    if (st_head == st_cnt) {   // stage the wave's next 64 paths
+                for (uint32_t pass = 0; pass < 6u && need != 0u; ++pass) {   // (a batch of 16 serves at most 16 lanes)
+                    if (st_head == st_cnt) {   // stage the wave's next paths
                         // The wave draws path indices from the call's counter a chunk at a time (one returning atomic on a single word
                         // per bounce of every wave would be the whole chip's atomic rate several times over); chunks shrink towards the
                         // end of the call so that no wave is left with a long tail of its own.
@@ -1825,7 +1826,7 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
                             }
                         }
                         const unsigned long long in_chunk = chunk_end - chunk_next;
-                        const uint32_t got = in_chunk < 64ull ? (uint32_t)in_chunk : 64u;
+                        const uint32_t got = in_chunk < (unsigned long long)batch ? (uint32_t)in_chunk : batch;
                         if (got == 0u) break;   // nothing left for this wave
                         const unsigned long long first = chunk_next;
                         chunk_next += got;
@@ -2056,18 +2057,18 @@ void launch_render_persistent(const DRenderParams* params, const DRenderParams& 
 }
 // The resident form (k_render_resident): one 1024-thread block per CU like the WIDE form, for scenes it can take (see
 // resident_form_fits); 0 if the kernel cannot be resident with that much LDS.
-// LDS of the resident form: the scene's tables and, per wave, 64 staged primary rays
-static size_t resident_lds_bytes(const DScene& sc) { return persistent_lds_bytes(sc, 3u, true) + (size_t)(WIDE_BLOCK / 64u) * 64u * RESIDENT_STAGE_BYTES; }
-uint32_t resident_waves_per_cu(const DScene& sc) {
+// LDS of the resident form: the scene's tables and, per wave, `batch` staged primary rays
+static size_t resident_lds_bytes(const DScene& sc, uint32_t batch) { return persistent_lds_bytes(sc, 3u, true) + (size_t)(WIDE_BLOCK / 64u) * batch * RESIDENT_STAGE_BYTES; }
+uint32_t resident_waves_per_cu(const DScene& sc, uint32_t batch) {
     int nb = 0;
-    const size_t lds = resident_lds_bytes(sc);
+    const size_t lds = resident_lds_bytes(sc, batch);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render_resident<false>, WIDE_BLOCK, lds) != hipSuccess || nb < 1) return 0u;
     return (uint32_t)nb * (WIDE_BLOCK / 64);
 }
 void launch_render_resident(const DRenderParams* params, const DRenderParams& host_params, hipStream_t s) {
     const uint32_t block_waves = WIDE_BLOCK / 64;
     dim3 g((host_params.n_sub + block_waves - 1) / block_waves), b(WIDE_BLOCK);
-    const size_t lds = resident_lds_bytes(host_params.sc);
+    const size_t lds = resident_lds_bytes(host_params.sc, host_params.resident_batch);
     if (host_params.sc.batch_undecided != 0u) hipLaunchKernelGGL((k_render_resident<true>), g, b, lds, s, params);
     else hipLaunchKernelGGL((k_render_resident<false>), g, b, lds, s, params);
 }
