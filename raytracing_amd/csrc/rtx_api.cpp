@@ -612,27 +612,32 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         PathPool* pp = sc->lane(0);
         uint32_t mode = lds_mode_for(sc, flags);
         bool lds_recs = false;   // the shade records next to the surface tables, where there is room
+        // Scenes that sit in LDS whole (tree, surface tables and shade records) can take the resident form of the kernel: paths stay
+        // in registers from bounce to bounce and the pool below holds nothing.  It is the faster form where paths bounce (the headline
+        // frame: 157 against 177 ms; a 62-spp call 20.2 against 23.2 ms; simple_light 4.2 against 6.7 ms, demo_spheres 1.8 against
+        // 2.4) and the slower one where nearly every path ends at its first ray (a sparse soup in front of the sky: 2.6 against 2.2 ms
+        // for a 16-spp call; hello_triangle 0.6 against 0.3 ms), so the scene's last call decides: 1.5 rays per path or more.  Scenes
+        // whose undecided box tests are batched (thin boxes: the Cornell box, 125 against 104 ms per 500 spp) keep the pooled form, as do
+        // a scene's first call and calls that count work (the counters exist in the pooled form only).  RTX_RESIDENT=0 / 1 forces one.
+        const char* force_form = std::getenv("RTX_RESIDENT");
+        const bool want_resident = !(flags & (RTX_FLAG_COUNT_WORK | RTX_FLAG_NO_LDS)) &&
+                                   ((force_form && *force_form) ? std::atoi(force_form) != 0 : (sc->rays_per_path >= 1.5 && !sc->d.batch_undecided));
+        const size_t wide_limit = env_u32("RTX_LDS_WIDE_BYTES", 150u * 1024u, true);
         if (mode <= 1u && !(flags & RTX_FLAG_NO_LDS)) {
             // What does not fit in LDS five times per CU may fit once: one 1024-thread block per CU then holds the tree, and the surface
             // tables if there is room, for sixteen waves (RTX_LDS_WIDE_BYTES: the most LDS such a block may take, 0 = never).
-            const size_t wide_limit = env_u32("RTX_LDS_WIDE_BYTES", 150u * 1024u, true);
             if (persistent_lds_bytes(sc->d, 3u, false) <= wide_limit) mode = 3u;
             else if (mode == 0u && persistent_lds_bytes(sc->d, 4u, false) <= wide_limit) mode = 4u;
             if (mode == 3u) lds_recs = persistent_lds_bytes(sc->d, 3u, true) <= wide_limit;
+        } else if (mode == 2u && want_resident && persistent_lds_bytes(sc->d, 3u, true) <= wide_limit) {
+            mode = 3u;   // a small scene: the resident form exists as one block per CU only
+            lds_recs = true;
         }
         if (mode == 2u) lds_recs = persistent_lds_bytes(sc->d, 2u, true) <= env_u32("RTX_LDS_SCENE_BYTES", 32u * 1024u);
         if (env_u32("RTX_LDS_RECS", 1, true) == 0u) lds_recs = false;
-        // Scenes that sit in LDS whole (tree, surface tables and shade records) can take the resident form: paths stay in registers
-        // from bounce to bounce and the pool below holds nothing.  It is the faster form where paths bounce (the headline frame:
-        // 171.7 against 177.3 ms, a 62-spp call 22.1 against 23.2 ms) and the slower one where nearly every path ends at its first
-        // ray (a sparse soup in front of the sky: 2.6 against 2.2 ms for a 16-spp call), so the scene's last call decides: 1.5 rays
-        // per path or more.  A scene's first call, calls that count work (the counters exist in the pooled form only) and
-        // RTX_RESIDENT=0 take the pooled form; RTX_RESIDENT=1 forces the resident one.
-        const char* force_form = std::getenv("RTX_RESIDENT");
-        const bool want_resident = (force_form && *force_form) ? std::atoi(force_form) != 0 : sc->rays_per_path >= 1.5;
         // (its waves stage the primary rays they make in LDS, 64 at a time where there is room, else 48, 32 or 16)
         uint32_t resident_waves = 0u, resident_batch = 0u;
-        if (mode == 3u && lds_recs && !(flags & RTX_FLAG_COUNT_WORK) && want_resident)
+        if (mode == 3u && lds_recs && want_resident)
             for (uint32_t b : {64u, 48u, 32u, 16u}) {
                 resident_waves = resident_waves_per_cu(sc->d, b);
                 resident_batch = b;
