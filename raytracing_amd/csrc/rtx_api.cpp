@@ -623,6 +623,31 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         const bool want_resident = !(flags & (RTX_FLAG_COUNT_WORK | RTX_FLAG_NO_LDS)) &&
                                    ((force_form && *force_form) ? std::atoi(force_form) != 0 : (sc->rays_per_path >= 1.5 && !sc->d.batch_undecided));
         const size_t wide_limit = env_u32("RTX_LDS_WIDE_BYTES", 150u * 1024u, true);
+        // A scene's first call knows no rays per path yet.  Where the answer matters (the scene could take the resident form and the
+        // call is long enough to gain by it) the call's first sample goes ahead as a call of its own, which measures it, and the
+        // other samples follow in the form that suits: the reference renders one frame per process, so its first call is its only one.
+        if (sc->rays_per_path == 0.0 && !no_wait && !(force_form && *force_form) && !(flags & (RTX_FLAG_COUNT_WORK | RTX_FLAG_NO_LDS)) &&
+            !sc->d.batch_undecided && spp_count >= 8u && persistent_lds_bytes(sc->d, 3u, true) <= wide_limit &&
+            resident_waves_per_cu(sc->d, 16u) != 0u && env_u32("RTX_PROBE_FIRST_CALL", 1, true) != 0u) {
+            rtx_stats first{}, rest{};
+            rc = rtx_render_accumulate(sc, cam, seed, spp_begin, 1u, flags, d_accum, stream, &first);
+            if (rc != RTX_OK) return rc;
+            if (sc->rays_per_path == 0.0) sc->rays_per_path = 1.0;   // (cannot be: a path is at least one ray)
+            rc = rtx_render_accumulate(sc, cam, seed, spp_begin + 1u, spp_count - 1u, flags, d_accum, stream, &rest);
+            if (rc != RTX_OK) return rc;
+            if (stats) {
+                *stats = rest;
+                stats->ms_total += first.ms_total;
+                stats->paths += first.paths;
+                stats->rays += first.rays;
+                stats->node_visits += first.node_visits;
+                stats->sphere_tests += first.sphere_tests;
+                stats->planar_tests += first.planar_tests;
+                stats->box_fallbacks += first.box_fallbacks;
+                if (first.iterations > stats->iterations) stats->iterations = first.iterations;
+            }
+            return RTX_OK;
+        }
         if (mode <= 1u && !(flags & RTX_FLAG_NO_LDS)) {
             // What does not fit in LDS five times per CU may fit once: one 1024-thread block per CU then holds the tree, and the surface
             // tables if there is room, for sixteen waves (RTX_LDS_WIDE_BYTES: the most LDS such a block may take, 0 = never).

@@ -375,6 +375,43 @@ def test_paths_resident_in_registers_render_the_same_image(rt, oracle, form, mon
     assert np.array_equal(bits(got + 0.0), bits(want + 0.0))
 
 
+def test_first_call_of_a_scene_measures_its_rays_per_path_with_its_first_sample(rt, oracle, monkeypatch):
+    """A scene's first render call of eight samples or more runs its first sample as a launch of its own (which tells how many
+    rays a path of the scene traces) and the others in the form that suits: the image and the ray count are those of the oracle
+    and of the same call with that turned off, the device time covers both launches, and a second call gives the same image."""
+    import torch
+
+    surfaces, cam = S.cover_spheres()
+    cam = dict(cam, image_width=160)
+    icam = rt.camera_initialize(cam)
+    stream = torch.cuda.current_stream().cuda_stream
+    images, stats = [], []
+    for probe in ("1", "0", "1"):
+        monkeypatch.setenv("RTX_PROBE_FIRST_CALL", probe)
+        dev = rt.Scene(rt.HostBVH(surfaces))
+        acc = torch.zeros(icam.image_height, icam.image_width, 3, dtype=torch.float64, device="cuda")
+        stats.append(dev.render_accumulate(icam, 9, 5, 12, acc.data_ptr(), stream))
+        images.append(acc.cpu().numpy())
+        if probe == "1":
+            again = torch.zeros_like(acc)
+            st2 = dev.render_accumulate(icam, 9, 5, 12, again.data_ptr(), stream)
+            assert st2.rays == stats[-1].rays
+            assert np.allclose(again.cpu().numpy(), images[-1], rtol=1e-13, atol=0)
+        dev.close()
+    want, ctr = oracle.Scene(surfaces).render(oracle.camera_initialize(cam), 9, 5, 12, iterative=True)
+    for img, st in zip(images, stats):
+        assert st.rays == ctr.rays and st.paths == ctr.paths == 160 * 90 * 12
+        assert st.ms_total > 0
+        assert np.allclose(img, want, rtol=1e-13, atol=0)
+    # fewer than eight samples: one launch, as before
+    dev = rt.Scene(rt.HostBVH(surfaces))
+    acc = torch.zeros(icam.image_height, icam.image_width, 3, dtype=torch.float64, device="cuda")
+    st = dev.render_accumulate(icam, 9, 5, 7, acc.data_ptr(), stream)
+    want7, ctr7 = oracle.Scene(surfaces).render(oracle.camera_initialize(cam), 9, 5, 7, iterative=True)
+    assert st.rays == ctr7.rays
+    assert np.allclose(acc.cpu().numpy(), want7, rtol=1e-13, atol=0)
+
+
 def test_depth_limit_and_pool_smaller_than_job(rt, oracle, monkeypatch):
     surfaces, cam = S.cornell_box()
     for max_depth in (1, 2, 7):
