@@ -618,7 +618,8 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         // 2.4) and the slower one where nearly every path ends at its first ray (a sparse soup in front of the sky: 2.6 against 2.2 ms
         // for a 16-spp call; hello_triangle 0.6 against 0.3 ms), so the scene's last call decides: 1.5 rays per path or more.  Scenes
         // whose undecided box tests are batched (thin boxes: the Cornell box, 125 against 104 ms per 500 spp) keep the pooled form, as do
-        // a scene's first call and calls that count work (the counters exist in the pooled form only).  RTX_RESIDENT=0 / 1 forces one.
+        // a scene's first call (but see the probe below) and calls that count work (the counters exist in the pooled form only).
+        // RTX_RESIDENT=0 / 1 forces one.
         const char* force_form = std::getenv("RTX_RESIDENT");
         const bool want_resident = !(flags & (RTX_FLAG_COUNT_WORK | RTX_FLAG_NO_LDS)) &&
                                    ((force_form && *force_form) ? std::atoi(force_form) != 0 : (sc->rays_per_path >= 1.5 && !sc->d.batch_undecided));
