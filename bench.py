@@ -44,7 +44,7 @@ SEED, SCENE_SEED = 0xC0FFEE, 0xC0FFEE
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (spec)
 FP64_VECTOR_PEAK_TF = 78.6   # MI355X vector FP64 peak (spec), 2 flop per FMA lane
 KERNEL = "k_render_persistent"     # the single launch with its paths in a pool ...
-KERNEL_RESIDENT = "k_render_resident"   # ... or in registers (scenes that sit in LDS whole, from a scene's second call on, where paths bounce)
+KERNEL_RESIDENT = "k_render_resident"   # ... or in registers (scenes that sit in LDS whole, where paths bounce)
 
 
 def frame_kernel(names):
