@@ -1767,6 +1767,9 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
     uint32_t events = 0;
     uint32_t c_nodes = 0, c_sph = 0, c_pln = 0, c_fallback = 0;
     WalkProfile prof;
+#ifdef RTX_PROBE_NO_ATOMICS
+    V3 probe_sum = v3(0, 0, 0);
+#endif
     for (;;) {
         const bool walked = have && node >= end;   // the ray has its closest hit (or none): the path's next bounce is due
         const uint32_t n_walked = (uint32_t)__popcll(ballot64(walked));
@@ -1785,10 +1788,15 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
             const Bounce bo = bounce_wave(sc, lds_recs, seed, max_depth, background, walked, best_leaf, tmax, o, d, beta, pixel, sample, draw, depth);
             if (walked) {
                 if (bo.add) {
+#ifdef RTX_PROBE_NO_ATOMICS
+                    // Pricing probe (wrong image, same work): what do the frame's scattered atomics cost?
+                    probe_sum = probe_sum + bo.radiance;
+#else
                     double* px = accum + 3 * (size_t)pixel;
                     if (bo.radiance.x != 0.0) unsafeAtomicAdd(px + 0, bo.radiance.x);
                     if (bo.radiance.y != 0.0) unsafeAtomicAdd(px + 1, bo.radiance.y);
                     if (bo.radiance.z != 0.0) unsafeAtomicAdd(px + 2, bo.radiance.z);
+#endif
                 }
                 if (bo.alive) {
                     o = bo.p; d = bo.nd; beta = bo.beta; draw = bo.draw; depth = bo.depth;
@@ -1879,6 +1887,11 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
         walk_pass<false, true, BATCH, false>(sc, w, have, o, d, rdiv, rf, tmin, tmax, best_leaf, node, end, PEND_AT, scene_filter, c_nodes, c_sph, c_pln,
                                              c_fallback, prof);
     }
+#ifdef RTX_PROBE_NO_ATOMICS
+    unsafeAtomicAdd(accum + 3 * (size_t)lane + 0, probe_sum.x);
+    unsafeAtomicAdd(accum + 3 * (size_t)lane + 1, probe_sum.y);
+    unsafeAtomicAdd(accum + 3 * (size_t)lane + 2, probe_sum.z);
+#endif
     if (lane == 0) {
         atomicAdd(&ctl->rays, n_rays);
         atomicMax(&ctl->rounds_max, events);

@@ -507,6 +507,44 @@ def test_headline_size_properties(rt, oracle):
     assert np.array_equal(img[0, 0], [0.7, 0.8, 1.0])
 
 
+def test_headline_frame_in_both_forms_of_the_kernel(rt, oracle, monkeypatch):
+    """cover_spheres at the benchmark's 1920x1080 in the form the benchmark times (paths resident in registers) and in the
+    pooled form: the same rays, paths and image (up to the order of the f64 sums) at 9 samples per pixel -- 1.9e7 paths, so
+    the resident form's chunks of path indices run through their whole range of sizes, down to 64 at the end of the call --
+    the same again for a fresh scene whose first call goes through the first-sample probe, and the whole frame at one sample
+    per pixel against the oracle bit for bit."""
+    import torch
+
+    surfaces, cam = S.cover_spheres(image_width=1920)
+    icam = rt.camera_initialize(cam)
+    assert (icam.image_width, icam.image_height) == (1920, 1080)
+    stream = torch.cuda.current_stream().cuda_stream
+    bvh = rt.HostBVH(surfaces)
+
+    def frame(resident, begin, count):
+        if resident is None:
+            monkeypatch.delenv("RTX_RESIDENT", raising=False)
+        else:
+            monkeypatch.setenv("RTX_RESIDENT", resident)
+        dev = rt.Scene(bvh)
+        acc = torch.zeros(1080, 1920, 3, dtype=torch.float64, device="cuda")
+        st = dev.render_accumulate(icam, 0xC0FFEE, begin, count, acc.data_ptr(), stream)
+        dev.close()
+        return acc, st
+
+    res, st_res = frame("1", 3, 9)
+    pool, st_pool = frame("0", 3, 9)
+    probed, st_probed = frame(None, 3, 9)   # a scene's first call: sample 3 as a pooled launch of its own, samples 4..11 resident
+    assert st_res.paths == st_pool.paths == st_probed.paths == 9 * 1920 * 1080
+    assert st_res.rays == st_pool.rays == st_probed.rays and st_res.rays > 2 * st_res.paths
+    assert torch.allclose(res, pool, rtol=1e-13, atol=0) and torch.allclose(res, probed, rtol=1e-13, atol=0)
+    assert int((res.sum(dim=2) == 0).sum()) == 0   # every pixel of this scene receives light: none was skipped
+    one, st_one = frame("1", 41, 1)
+    want, ctr = oracle.Scene(surfaces).render(oracle.camera_initialize(cam), 0xC0FFEE, 41, 1, iterative=True)
+    assert st_one.rays == ctr.rays and st_one.paths == ctr.paths == 1920 * 1080
+    assert np.array_equal(bits(one.cpu().numpy() + 0.0), bits(want + 0.0))
+
+
 # ------------------------------------------------------------------ converged images
 def test_hello_triangle_golden_png(rt):
     from PIL import Image
