@@ -126,12 +126,15 @@ typedef struct rtx_build_stats {
 } rtx_build_stats;
 
 /* flags for rtx_render_accumulate / rtx_trace_closest */
-#define RTX_FLAG_COUNT_WORK   1u  /* fill node_visits / *_tests (slower) */
+#define RTX_FLAG_COUNT_WORK   1u  /* fill node_visits / *_tests with the box and surface tests of the reference's walk (slower) */
 #define RTX_FLAG_TIME_KERNELS 2u  /* render with the round loop (generate / traverse / shade launches) and time every launch with HIP events */
 #define RTX_FLAG_EXACT_DIVIDE 4u  /* box test by six true divisions per node, exactly as src/aabb.rs:55-76 */
 #define RTX_FLAG_F64_FILTER   8u  /* skip the single-precision tier of the box test */
 #define RTX_FLAG_NO_LDS       16u /* keep the f32 node records in global memory even when they fit in LDS */
 #define RTX_FLAG_NO_WAIT      32u /* rtx_render_accumulate only: enqueue the work on `stream` and return; no stats */
+#define RTX_FLAG_COUNT_ACTUAL 64u /* fill node_visits / *_tests with the tests this library's walk makes.  They can be fewer than
+                                     the reference's (RTX_FLAG_COUNT_WORK): the walk culls quads and triangles with boxes smaller
+                                     than the reference's padded ones (src/aabb.rs:78-87) where that provably leaves every hit as it is */
 
 /* Message of the calling thread's last failed call. */
 const char* rtx_last_error(void);

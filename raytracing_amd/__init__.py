@@ -33,6 +33,7 @@ FLAG_EXACT_DIVIDE = 4
 FLAG_F64_FILTER = 8
 FLAG_NO_LDS = 16
 FLAG_NO_WAIT = 32
+FLAG_COUNT_ACTUAL = 64
 TRACE_DEVICE_MAX_RAYS = 1 << 20
 
 BISECT, MIDPOINT, SAH_EQUAL_SIZE, SAH_PER_SURFACE = 0, 1, 2, 3

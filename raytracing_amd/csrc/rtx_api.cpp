@@ -143,14 +143,14 @@ static uint32_t lds_mode_for(const rtx_scene* sc, uint32_t flags) {
 // whose box planes are too large for f32, or on request).
 void rtx::run_traverse(const rtx_scene* sc, const DState& rays, const DHits& hits, const DPool& pool, double tmin, double tmax,
                        uint32_t flags, DRenderCtl* ctl, hipStream_t s) {
-    const bool count_work = (flags & RTX_FLAG_COUNT_WORK) != 0;
-    if (flags & RTX_FLAG_EXACT_DIVIDE) {
+    const bool count_work = counting(flags);
+    if (flags & RTX_FLAG_EXACT_DIVIDE) {   // (the f64 forms read the reference's boxes only)
         launch_traverse(sc->d, rays, hits, pool, tmin, tmax, ctl, count_work, true, s);
     } else if ((flags & RTX_FLAG_F64_FILTER) || !sc->f32_ok) {
         launch_traverse(sc->d, rays, hits, pool, tmin, tmax, ctl, count_work, false, s);
     } else {
         const uint32_t mode = lds_mode_for(sc, flags);
-        launch_traverse_f32(sc->d, rays, hits, pool, tmin, tmax, ctl, count_work, mode, s);
+        launch_traverse_f32(scene_tables(sc, flags), rays, hits, pool, tmin, tmax, ctl, count_work, mode, s);
     }
 }
 
@@ -303,16 +303,99 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
         nodes32[i].miss = nd.miss * 32u;
     }
 
+    // ---- the boxes the walk's first tier tests ("cull boxes")
+    // The reference pads the box of every quad and triangle by its own extent on each side (AABB::padded, src/aabb.rs:78-87):
+    // a ray through such a box usually misses the surface, and the boxes of neighbours overlap many times over.  The walk may
+    // cull with a smaller box C(node) as long as its outcome stays the reference's, which holds when, for every node,
+    //   (a) C is inside the reference's box R componentwise.  The reference's f64 evaluation of its predicate is monotone in
+    //       the box (RN is monotone, the quotients share the divisor, max/min/clamp are monotone), so "the predicate holds on C"
+    //       implies "it holds on R": where the first tier proves a hit on C the reference passes the node too;
+    //   (b) a ray for which the predicate fails on C, at the interval's current upper end, can have no accepted hit below the
+    //       node at that or any smaller upper end.  Skipping the subtree then changes nothing the walk carries (best hit,
+    //       interval), and the upper end only shrinks, so the rest of the walk is the reference's.
+    // Leaves of two kinds satisfy (b).  "Margin" leaves: a quad or triangle whose C is the box of its true corners grown by
+    // at least 1e-9 of the largest coordinate and 1e-6 of the surface's extent -- far more than the rounding of the surface
+    // test, so an accepted hit point lies strictly inside C and the ray's slab intervals on C contain its t with room.
+    // "Reference" leaves (spheres; planar surfaces whose reference box does not contain their corners with that room, which
+    // the reference's two-corner quad boxes allow): C = R, and the reference itself tests R before the surface.  An internal
+    // node takes the union of its children's C (if that lies inside its R, else R): a margin leaf below is covered by the
+    // margin argument, a reference leaf below by monotonicity (its R = C lies inside the union, so the predicate failing on
+    // the union implies it fails on that R, and the reference culls the leaf itself).
+    // Visits the first tier cannot decide go to the f64 tiers with the reference's own box, as before.  Only the numbers of
+    // box and surface tests change, so calls that count the reference's work (RTX_FLAG_COUNT_WORK) walk tables made from R.
+    // C is kept thick enough for single precision to resolve (2^-13 of the largest coordinate per side, R permitting).
+    const bool want_cull = env_u32("RTX_TIGHT_BOXES", 1, true) != 0u;
+    std::vector<DBox64> cull(n);
+    uint32_t n_cull = 0;   // nodes whose cull box differs from the reference's
+    for (uint32_t i = n; i-- > 0u;) {
+        DBox64& c = cull[i];
+        const DNode& nd = nodes[i];
+        for (int a = 0; a < 3; ++a) {
+            c.bmin[a] = nd.bmin[a];
+            c.bmax[a] = nd.bmax[a];
+        }
+        if (!want_cull) continue;
+        const uint32_t prim = desc->node_prim[i];
+        double lo[3], hi[3];
+        bool ok = true;
+        if (prim != RTX_NONE) {
+            if (prims[prim].kind == RTX_SPHERE) continue;
+            const DPlanar& g = planars[prims[prim].slot];
+            const bool quad = prims[prim].kind == RTX_QUAD;
+            for (int a = 0; a < 3 && ok; ++a) {
+                const double p0 = g.q[a], p1 = g.q[a] + g.u[a], p2 = g.q[a] + g.v[a], p3 = quad ? g.q[a] + g.u[a] + g.v[a] : p0;
+                const double tlo = std::fmin(std::fmin(p0, p1), std::fmin(p2, p3)), thi = std::fmax(std::fmax(p0, p1), std::fmax(p2, p3));
+                const double big = std::fmax(std::fabs(nd.bmin[a]), std::fabs(nd.bmax[a]));
+                const double need = std::fmax(1e-9 * big, 1e-6 * (std::fabs(g.u[a]) + std::fabs(g.v[a]))) + 1e-300;
+                const double grow = std::fmax(need, 0x1.0p-13 * big);
+                lo[a] = std::fmax(tlo - grow, nd.bmin[a]);
+                hi[a] = std::fmin(thi + grow, nd.bmax[a]);
+                ok = tlo - lo[a] >= need && hi[a] - thi >= need;   // (false for a NaN anywhere)
+            }
+        } else {
+            const DBox64 &l = cull[i + 1], &r = cull[desc->node_right[i]];
+            for (int a = 0; a < 3 && ok; ++a) {
+                lo[a] = std::fmin(l.bmin[a], r.bmin[a]);
+                hi[a] = std::fmax(l.bmax[a], r.bmax[a]);
+                ok = lo[a] >= nd.bmin[a] && hi[a] <= nd.bmax[a];
+            }
+        }
+        if (!ok) continue;
+        bool differs = false;
+        for (int a = 0; a < 3; ++a) {
+            differs = differs || lo[a] != nd.bmin[a] || hi[a] != nd.bmax[a];
+            c.bmin[a] = lo[a];
+            c.bmax[a] = hi[a];
+        }
+        if (differs) ++n_cull;
+    }
+    // f32 records of the cull boxes; `nodes32` keeps the reference's planes for the calls that count its work
+    std::vector<DNode32> nodes32_cull;
+    if (n_cull) {
+        nodes32_cull = nodes32;
+        thin_nodes = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            bool thin = false;
+            for (int a = 0; a < 3; ++a) {
+                nodes32_cull[i].plane[2 * a] = (float)cull[i].bmin[a];
+                nodes32_cull[i].plane[2 * a + 1] = (float)cull[i].bmax[a];
+                if (cull[i].bmax[a] - cull[i].bmin[a] <= 0x1.0p-16 * std::fmax(std::fabs(cull[i].bmin[a]), std::fabs(cull[i].bmax[a]))) thin = true;
+            }
+            if (thin) ++thin_nodes;
+        }
+    }
+
     // Quantised half-size records for trees that are walked from global memory: a grid of 2^16 steps over the extent of
     // all boxes per axis, every plane rounded to the nearest step.  The walk's error bound rests on
     // |q_org + q * delta - plane| <= delta / 2 (1 + 1e-4): checked here plane by plane, and a scene that fails it
     // (extents too small against their offset for f64 to resolve the steps) keeps the f32 records.
-    std::vector<DNode16> nodes16;
+    std::vector<DNode16> nodes16, nodes16_ref;   // of the cull boxes / of the reference's boxes (only where they differ)
     double q_org[3] = {0, 0, 0};
     float q_delta[3] = {0, 0, 0};
     bool q16_ok = f32_ok && filter_ok && n > 0;
     if (q16_ok) {
         nodes16.resize(n);
+        if (n_cull) nodes16_ref.resize(n);
         for (int a = 0; a < 3 && q16_ok; ++a) {
             double lo = nodes[0].bmin[a], hi = nodes[0].bmax[a];
             for (uint32_t i = 1; i < n; ++i) {
@@ -324,17 +407,23 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
             if (!(hi >= lo) || !std::isfinite(q_delta[a]) || (hi > lo && !(q_delta[a] >= 1e-30f))) q16_ok = false;
             const double dl = (double)q_delta[a];
             for (uint32_t i = 0; i < n && q16_ok; ++i) {
-                const double planes[2] = {nodes[i].bmin[a], nodes[i].bmax[a]};
-                for (int k = 0; k < 2; ++k) {
+                const double planes[4] = {cull[i].bmin[a], cull[i].bmax[a], nodes[i].bmin[a], nodes[i].bmax[a]};
+                for (int k = 0; k < (n_cull ? 4 : 2); ++k) {
                     const double q = dl > 0.0 ? std::nearbyint((planes[k] - lo) / dl) : 0.0;
                     if (!(q >= 0.0 && q <= 65535.0) || !(std::fabs(lo + q * dl - planes[k]) <= 0.50005 * dl)) q16_ok = false;
-                    else nodes16[i].q[2 * a + k] = (uint16_t)q;
+                    else if (k < 2) nodes16[i].q[2 * a + k] = (uint16_t)q;
+                    else nodes16_ref[i].q[2 * a + k - 2] = (uint16_t)q;
                 }
             }
         }
-        for (uint32_t i = 0; i < n && q16_ok; ++i)
+        for (uint32_t i = 0; i < n && q16_ok; ++i) {
             nodes16[i].link = nodes[i].prim != NONE ? nodes[i].prim : (NODE16_INTERNAL | nodes[i].miss);
-        if (!q16_ok) nodes16.clear();
+            if (n_cull) nodes16_ref[i].link = nodes16[i].link;
+        }
+        if (!q16_ok) {
+            nodes16.clear();
+            nodes16_ref.clear();
+        }
     }
 
     // Many box tests of such a scene are left to the f64 tiers: the walk then collects those lanes and resolves
@@ -386,7 +475,10 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
                 const double room = std::fmax(1e-9 * big, 1e-6 * c.ext[a]) + 1e-300;
                 inside = c.lo[a] - nodes[i].bmin[a] >= room && nodes[i].bmax[a] - c.hi[a] >= room;
             }
-            if (inside) nodes32[i].miss |= 1u;
+            if (inside) {
+                nodes32[i].miss |= 1u;
+                if (n_cull) nodes32_cull[i].miss |= 1u;
+            }
         }
     }
 
@@ -409,7 +501,13 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     UP(nodes, nodes);
     UP(spheres, spheres);
     UP(planars, planars);
-    UP(nodes32, nodes32);
+    if (n_cull) {
+        UP(nodes32, nodes32_cull);
+        UP(nodes32_ref, nodes32);
+        UP(nodes16_ref, nodes16_ref);
+    } else {
+        UP(nodes32, nodes32);
+    }
     UP(leaf_codes, leaf_codes);
     UP(nodes16, nodes16);
     UP(boxes64, boxes64);
@@ -453,6 +551,12 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     sc->d.rec_user_id = sc->rec_user_id.p;
     sc->d.shade_recs = sc->shade_recs.p;
     sc->f32_ok = f32_ok && filter_ok && n < (1u << 25);   // the f32 walk keeps two flags above a record's byte offset (n * 32 < 2^30)
+    sc->n_cull = n_cull;
+    sc->d_ref = sc->d;   // the same scene with the reference's boxes in the first tier's records: what counting calls walk
+    if (n_cull) {
+        sc->d_ref.nodes32 = sc->nodes32_ref.p;
+        sc->d_ref.nodes16 = q16_ok ? sc->nodes16_ref.p : nullptr;
+    }
     if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
         return bail(fail(RTX_ERR_HIP, "hipEventCreate failed"));
     // Set-up of the allocation-free closest-hit entry: where this device keeps its copy of the scratch array.
@@ -600,7 +704,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
     if (total == 0 || cam->max_depth == 0) return RTX_OK;   // ray_color returns ZERO at remaining == 0 (camera.rs:190-192)
     if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(RTX_ERR_BAD_ARG, "rtx_render_accumulate: sample index overflow");
     const bool no_wait = (flags & RTX_FLAG_NO_WAIT) != 0;
-    if (no_wait && ((flags & (RTX_FLAG_EXACT_DIVIDE | RTX_FLAG_F64_FILTER | RTX_FLAG_TIME_KERNELS | RTX_FLAG_COUNT_WORK)) || !sc->f32_ok ||
+    if (no_wait && ((flags & (RTX_FLAG_EXACT_DIVIDE | RTX_FLAG_F64_FILTER | RTX_FLAG_TIME_KERNELS)) || counting(flags) || !sc->f32_ok ||
                     env_u32("RTX_PERSISTENT", 1, true) == 0u))
         return fail(RTX_ERR_BAD_ARG, "rtx_render_accumulate: RTX_FLAG_NO_WAIT needs the single-launch render (no other box-test tier, no timing or counting flags, a scene within the f32 tier's range)");
     HIP_TRY(hipSetDevice(sc->device));
@@ -621,13 +725,13 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         // a scene's first call (but see the probe below) and calls that count work (the counters exist in the pooled form only).
         // RTX_RESIDENT=0 / 1 forces one.
         const char* force_form = std::getenv("RTX_RESIDENT");
-        const bool want_resident = !(flags & (RTX_FLAG_COUNT_WORK | RTX_FLAG_NO_LDS)) &&
+        const bool want_resident = !counting(flags) && !(flags & RTX_FLAG_NO_LDS) &&
                                    ((force_form && *force_form) ? std::atoi(force_form) != 0 : (sc->rays_per_path >= 1.5 && !sc->d.batch_undecided));
         const size_t wide_limit = env_u32("RTX_LDS_WIDE_BYTES", 150u * 1024u, true);
         // A scene's first call knows no rays per path yet.  Where the answer matters (the scene could take the resident form and the
         // call is long enough to gain by it) the call's first sample goes ahead as a call of its own, which measures it, and the
         // other samples follow in the form that suits: the reference renders one frame per process, so its first call is its only one.
-        if (sc->rays_per_path == 0.0 && !no_wait && !(force_form && *force_form) && !(flags & (RTX_FLAG_COUNT_WORK | RTX_FLAG_NO_LDS)) &&
+        if (sc->rays_per_path == 0.0 && !no_wait && !(force_form && *force_form) && !counting(flags) && !(flags & RTX_FLAG_NO_LDS) &&
             !sc->d.batch_undecided && spp_count >= 8u && persistent_lds_bytes(sc->d, 3u, true) <= wide_limit &&
             resident_waves_per_cu(sc->d, 16u) != 0u && env_u32("RTX_PROBE_FIRST_CALL", 1, true) != 0u) {
             rtx_stats first{}, rest{};
@@ -688,7 +792,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         h.total_paths = total;
         DRenderParams& P = pp->h_params_ring[slot];
         P = DRenderParams{};
-        P.sc = sc->d;
+        P.sc = scene_tables(sc, flags);
         P.cam = to_dcamera(cam);
         P.st[0] = pp->state[0];
         P.st[1] = pp->state[1];
@@ -715,14 +819,14 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         HIP_TRY(hipEventRecord(pp->ring_ev[slot], s));   // the slot may be refilled once both uploads have executed
         HIP_TRY(hipEventRecord(sc->ev0, s));
         if (resident) launch_render_resident(pp->params.p, P, s);
-        else launch_render_persistent(pp->params.p, P, (flags & RTX_FLAG_COUNT_WORK) != 0, mode, s);
+        else launch_render_persistent(pp->params.p, P, counting(flags), mode, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(sc->ev1, s));
         if (no_wait) return RTX_OK;
         HIP_TRY(hipStreamSynchronize(s));
         DRenderCtl back;
         HIP_TRY(hipMemcpy(&back, pp->ctl.p, sizeof(back), hipMemcpyDeviceToHost));
-        if (total && !(flags & RTX_FLAG_COUNT_WORK)) sc->rays_per_path = (double)back.rays / (double)total;
+        if (total && !counting(flags)) sc->rays_per_path = (double)back.rays / (double)total;
         if (stats) {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, sc->ev0, sc->ev1);

@@ -134,6 +134,7 @@ struct DScene {
     double q_org[3];               // grid of the quantised planes: plane = q_org + q * q_delta
     float q_delta[3];
     uint32_t use16;                // the global-memory walk reads nodes16 instead of nodes32
+    uint32_t assume_in_count;      // counting instances of the walk take the shortcuts of the product's walk (they count its tests, not the reference's)
 };
 
 // State of the paths in flight, struct-of-arrays.  Entry i of every array

@@ -109,6 +109,10 @@ struct rtx_scene {
     rtx::DevBuf<rtx::DNode32> nodes32;
     rtx::DevBuf<uint32_t> leaf_codes;
     rtx::DevBuf<rtx::DNode16> nodes16;
+    rtx::DevBuf<rtx::DNode32> nodes32_ref;   // first-tier records of the reference's boxes, where the walk's cull boxes differ
+    rtx::DevBuf<rtx::DNode16> nodes16_ref;
+    rtx::DScene d_ref{};                      // `d` with those tables: what calls that count the reference's work walk
+    uint32_t n_cull = 0;                      // nodes whose cull box is smaller than the reference's
     rtx::DevBuf<rtx::DBox64> boxes64;
     rtx::DevBuf<uint32_t> rec_user_id;
     rtx::DevBuf<rtx::DShadeRec> shade_recs;
@@ -125,6 +129,15 @@ struct rtx_scene {
 };
 
 namespace rtx {
+
+// Calls that count work: RTX_FLAG_COUNT_WORK counts the reference's box and surface tests (the walk then uses the
+// reference's boxes in its first tier), RTX_FLAG_COUNT_ACTUAL the tests the product's walk really makes.
+inline bool counting(uint32_t flags) { return (flags & (RTX_FLAG_COUNT_WORK | RTX_FLAG_COUNT_ACTUAL)) != 0u; }
+inline DScene scene_tables(const rtx_scene* sc, uint32_t flags) {
+    DScene d = (flags & RTX_FLAG_COUNT_ACTUAL) || !(flags & RTX_FLAG_COUNT_WORK) ? sc->d : sc->d_ref;
+    d.assume_in_count = (flags & RTX_FLAG_COUNT_ACTUAL) ? 1u : 0u;
+    return d;
+}
 
 // Closest hit of the rays in `rays` (per-component arrays) cut into `pool`'s sub-pools, with the box-test tier
 // `flags` asks for; hit records go to `hits`.  `ctl` receives the work counters of RTX_FLAG_COUNT_WORK.

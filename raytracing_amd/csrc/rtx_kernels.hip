@@ -702,11 +702,12 @@ __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& 
         if (COUNT) ++c_nodes;
         bool hit;
         bool decided = box_hit_tier1<REC16>(planes, rf, hit);
-        if (BATCH && !COUNT && !REC16) {
+        if (BATCH && !REC16 && (!COUNT || sc.assume_in_count)) {
             // A node whose surfaces all lie inside its box with a margin (flagged when the scene was created): a hit of one
             // of them inside [tmin, tmax] implies that the box test passes, so where the f32 tier cannot decide the box the walk
             // goes on as if it had passed.  If the reference culls the node, nothing below it is hit and the outcome is the
-            // reference's; only the numbers of box and surface tests can differ, so the counting instances do not take this path.
+            // reference's; only the numbers of box and surface tests can differ, so the instances that count the reference's work
+            // do not take this path.
             const bool assume = !decided && contained && rf.tmin32 < rf.tmax32 && rf.K <= 3.0e38f;
             hit = hit || assume;
             decided = decided || assume;
@@ -1461,7 +1462,7 @@ __device__ __forceinline__ DScene uniform_scene(const DScene& s) {
     u.nodes16 = uniform_p(s.nodes16);
     u.boxes64 = uniform_p(s.boxes64); u.shade_recs = uniform_p(s.shade_recs); u.rec_user_id = uniform_p(s.rec_user_id);
     u.n_nodes = uniform32(s.n_nodes); u.filter_ok = uniform32(s.filter_ok); u.batch_undecided = uniform32(s.batch_undecided); u.pend_at = uniform32(s.pend_at); u.refill_at = uniform32(s.refill_at); u.bounce_at = uniform32(s.bounce_at);
-    u.n_spheres = uniform32(s.n_spheres); u.n_planars = uniform32(s.n_planars);
+    u.n_spheres = uniform32(s.n_spheres); u.n_planars = uniform32(s.n_planars); u.assume_in_count = uniform32(s.assume_in_count);
     return u;
 }
 __device__ RTX_PHASE_INLINE void phase_generate(const DRenderParams* pp, uint32_t parity, uint32_t slot0, unsigned long long first, uint32_t got) {

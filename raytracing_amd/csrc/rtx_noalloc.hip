@@ -58,7 +58,7 @@ extern "C" int rtx_trace_closest_device(rtx_scene* sc, const double* d_org, cons
     if (n > MAX_RAYS)
         return api_fail(RTX_ERR_BAD_ARG, "rtx_trace_closest_device: " + std::to_string(n) + " rays, the scratch array holds at most " +
                                              std::to_string(MAX_RAYS) + " (RTX_TRACE_DEVICE_MAX_RAYS); split the batch");
-    if (flags & (RTX_FLAG_COUNT_WORK | RTX_FLAG_TIME_KERNELS))
+    if (counting(flags) || (flags & RTX_FLAG_TIME_KERNELS))
         return api_fail(RTX_ERR_BAD_ARG, "rtx_trace_closest_device: counting and timing flags need rtx_trace_closest (there is no stats output here)");
     if (n == 0) return RTX_OK;
     HIP_TRY(hipSetDevice(sc->device));

@@ -1,0 +1,150 @@
+"""The walk culls quads and triangles with boxes smaller than the reference's padded ones (AABB::padded triples every
+extent, src/aabb.rs:78-87) wherever that provably leaves every hit as it is.  Here: ids and hit distances of the
+product's walk (no counting flag, so the smaller boxes are in use) against the oracle, bit for bit, through every form
+of the first tier; the walk's own test counts (RTX_FLAG_COUNT_ACTUAL) against the reference's (RTX_FLAG_COUNT_WORK,
+equal to the oracle's); quads whose reference box does not contain them (the two-corner box of src/geometry.rs:291-293
+under a rotation in the quad's plane), where the reference's clipping is part of the result; degenerate rays."""
+import numpy as np
+import pytest
+
+from raytracing_amd import scenes as S
+
+pytestmark = pytest.mark.gpu
+NONE = 0xFFFFFFFF
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def mixed_soup(n, seed):
+    """Triangles, quads (a third of them flat on an axis, a third rotated so that their corners leave the reference's box)
+    and spheres, interleaved."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        q = rng.uniform(-20.0, 20.0, 3)
+        mat = S.lambertian(rng.uniform(0.1, 0.9, 3))
+        k = i % 5
+        if k == 0:
+            out.append(S.sphere(q, rng.uniform(0.2, 1.5), mat))
+        elif k == 1:
+            out.append(S.triangle(q, rng.uniform(-2, 2, 3), rng.uniform(-2, 2, 3), mat))
+        elif k == 2:                       # flat on a coordinate axis
+            a = rng.integers(0, 3)
+            u, v = np.zeros(3), np.zeros(3)
+            u[(a + 1) % 3] = rng.uniform(0.5, 3.0)
+            v[(a + 2) % 3] = rng.uniform(0.5, 3.0)
+            out.append(S.quad(q, u, v, mat))
+        elif k == 3:                       # rotated by 45 degrees in its own plane: q+u and q+v lie outside box(q, q+u+v) padded
+            s = rng.uniform(0.5, 3.0)
+            out.append(S.quad(q, (s, 0.0, s), (-s, 0.0, s), mat))
+        else:
+            out.append(S.quad(q, rng.uniform(-2, 2, 3), rng.uniform(-2, 2, 3), mat))
+    return S.pack(out)
+
+
+def scene_of(name):
+    if name == "mixed_soup":
+        cam = S.camera(aspect_ratio=1.0, image_width=200, samples_per_pixel=1, max_depth=6, v_fov=50.0, look_from=(0.0, 0.0, -60.0),
+                       look_at=(0.0, 0.0, 0.0), background=(0.7, 0.8, 1.0))
+        return mixed_soup(3000, 3), cam
+    if name == "soup_triangles_30k":
+        surfaces, cam = S.synthetic_soup(n=30_000, kind="triangles", seed=5, image_width=256, samples_per_pixel=1)
+        return surfaces, dict(cam, max_depth=5)
+    surfaces, cam = S.EXAMPLES[name]()
+    return surfaces, dict(cam, image_width=min(cam["image_width"], 256))
+
+
+@pytest.mark.parametrize("form", ["lds", "global_f32", "global_q16"])
+@pytest.mark.parametrize("name", ["hello_triangle", "cornell_box", "quads", "simple_light", "mixed_soup", "soup_triangles_30k"])
+def test_walk_with_cull_boxes_gives_the_reference_hits(rt, oracle, name, form, monkeypatch):
+    if form == "global_q16":
+        monkeypatch.setenv("RTX_NODE16", "1")
+    lds_flag = 0 if form == "lds" else rt.FLAG_NO_LDS
+    surfaces, cam = scene_of(name)
+    dev, orc = rt.Scene(rt.HostBVH(surfaces)), oracle.Scene(surfaces)
+    icam = rt.camera_initialize(cam)
+    org, d = rt.primary_rays(icam, 3, 1)
+    rng = np.random.default_rng(5)
+    ref_tests = own_tests = 0
+    for bounce in range(3):
+        wid, wt, ctr = orc.trace_closest(org, d)
+        want_t = bits(np.where(wid == NONE, np.inf, wt))
+        ids, t, _ = dev.trace_closest(org, d, flags=lds_flag)                                  # the product's walk
+        assert np.array_equal(ids, wid) and np.array_equal(bits(t), want_t), f"bounce {bounce}"
+        ids, t, own = dev.trace_closest(org, d, flags=lds_flag | rt.FLAG_COUNT_ACTUAL)          # the same walk, counting
+        assert np.array_equal(ids, wid) and np.array_equal(bits(t), want_t), f"bounce {bounce} (counting)"
+        ids, t, ref = dev.trace_closest(org, d, flags=lds_flag | rt.FLAG_COUNT_WORK)            # the reference's walk
+        assert np.array_equal(ids, wid) and np.array_equal(bits(t), want_t)
+        assert [ref.node_visits, ref.sphere_tests, ref.planar_tests] == [ctr.node_visits, ctr.sphere_tests, ctr.planar_tests]
+        assert own.node_visits <= ref.node_visits and own.planar_tests <= ref.planar_tests and own.sphere_tests <= ref.sphere_tests
+        ref_tests += ref.node_visits + ref.planar_tests
+        own_tests += own.node_visits + own.planar_tests
+        hit = ids != NONE
+        if not hit.any():
+            break
+        org = org[hit] + d[hit] * t[hit, None]
+        d = rng.normal(size=org.shape) * rng.choice([1e-3, 1.0, 50.0], size=(len(org), 1))
+    print(f"{name} {form}: {own_tests} box + planar tests against the reference's {ref_tests}")
+    if name == "simple_light":        # (two spheres and one quad)
+        assert own_tests < ref_tests
+    elif name != "hello_triangle":    # (one leaf: its box is tested once per ray either way)
+        assert own_tests < 0.9 * ref_tests, (own_tests, ref_tests)
+    # with the smaller boxes turned off the walk's own counts are the reference's, except where it may skip an undecidable box test
+    monkeypatch.setenv("RTX_TIGHT_BOXES", "0")
+    dev0 = rt.Scene(rt.HostBVH(surfaces))
+    org, d = rt.primary_rays(icam, 3, 1)
+    _, _, off = dev0.trace_closest(org, d, flags=lds_flag | rt.FLAG_COUNT_ACTUAL)
+    _, _, ctr = orc.trace_closest(org, d)
+    assert off.planar_tests >= ctr.planar_tests and off.sphere_tests == ctr.sphere_tests
+
+
+def test_quads_outside_their_reference_box_are_clipped_as_the_reference_clips_them(rt, oracle):
+    """Quad::bounding_box is box(q, q + u + v) padded (src/geometry.rs:291-293): for u = (s, 0, s), v = (-s, 0, s) that is
+    the segment x = q.x, z in [q.z, q.z + 2s] grown by 1e-4 in x and by 2s in z, while the quad's corners q + u, q + v lie
+    at x = q.x +- s.  The reference never tests the quad for a ray that misses that box, so most of the quad is invisible.
+    The walk must keep that (such a leaf keeps the reference's box) and must not let a parent's smaller box hide what the
+    reference does see."""
+    s = 2.0
+    mat = S.lambertian((0.5, 0.5, 0.5))
+    surfaces = S.pack([
+        S.quad((0.0, 0.0, 0.0), (s, 0.0, s), (-s, 0.0, s), mat),
+        S.quad((10.0, 0.0, 0.0), (s, 0.0, s), (-s, 0.0, s), mat),
+        S.triangle((5.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0), mat),
+        S.quad((-6.0, 0.0, 1.0), (2.0, 0.0, 0.0), (0.0, 0.0, 2.0), mat),
+    ])
+    dev, orc = rt.Scene(rt.HostBVH(surfaces)), oracle.Scene(surfaces)
+    rng = np.random.default_rng(1)
+    n = 200_000
+    org = np.stack([rng.uniform(-8, 14, n), np.full(n, 5.0), rng.uniform(-2, 6, n)], axis=1)
+    d = np.stack([rng.normal(0, 0.05, n), np.full(n, -1.0), rng.normal(0, 0.05, n)], axis=1)
+    d[: n // 2, 0] = 0.0                                       # straight down: misses the sliver of a box unless x == q.x
+    d[: n // 2, 2] = 0.0
+    org[: n // 8, 0] = rng.choice([0.0, 10.0], n // 8) + rng.uniform(-2e-4, 2e-4, n // 8)   # ... so aim some at the sliver
+    wid, wt, _ = orc.trace_closest(org, d)
+    for flags in (0, rt.FLAG_NO_LDS):
+        ids, t, _ = dev.trace_closest(org, d, flags=flags)
+        assert np.array_equal(ids, wid) and np.array_equal(bits(t), bits(np.where(wid == NONE, np.inf, wt)))
+    over_quad0 = (np.abs(org[:, 0]) < 1.0) & (org[:, 2] > 1.0) & (org[:, 2] < 3.0) & (np.abs(d[:, 0]) == 0.0) & (np.abs(org[:, 0]) > 1e-3)
+    assert over_quad0.sum() > 100 and (wid[over_quad0] == NONE).all()      # geometrically over the quad, invisible in the reference
+    assert (wid == 0).sum() > 100 and (wid == 2).sum() > 100 and (wid == 3).sum() > 100
+
+
+def test_cull_boxes_and_degenerate_rays(rt, oracle):
+    """Zero, tiny, huge and non-finite direction components, origins on box faces and far away."""
+    surfaces = mixed_soup(2000, 11)
+    dev, orc = rt.Scene(rt.HostBVH(surfaces)), oracle.Scene(surfaces)
+    rng = np.random.default_rng(2)
+    n = 60000
+    org = rng.uniform(-25, 25, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d[rng.random((n, 3)) < 0.3] = 0.0
+    org[: n // 4] = np.round(org[: n // 4])
+    org[n // 4: n // 4 + 500] *= 1e6
+    d[-8:] = [[np.inf, 1, 1], [np.nan, 0, 1], [1e-320, 1, 0], [1e305, 1, 1], [0, 0, 0], [-0.0, 1, 0], [1, -np.inf, 0], [1e-310, 1e-310, 1e-310]]
+    wid, wt, _ = orc.trace_closest(org, d)
+    for flags in (0, rt.FLAG_NO_LDS):
+        ids, t, _ = dev.trace_closest(org, d, flags=flags)
+        assert np.array_equal(ids, wid) and np.array_equal(bits(t), bits(np.where(wid == NONE, np.inf, wt)))
+    assert (wid != NONE).sum() > 1000

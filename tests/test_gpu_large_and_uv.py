@@ -45,6 +45,12 @@ def test_million_surface_scene_against_the_oracle(rt, oracle, kind):
         assert np.array_equal(ids, wid), f"bounce {bounce}: {np.count_nonzero(ids != wid)} ids differ"
         assert np.array_equal(bits(t), bits(np.where(wid == NONE, np.inf, wt))), f"bounce {bounce}"
         assert [st.node_visits, st.sphere_tests, st.planar_tests] == [ctr.node_visits, ctr.sphere_tests, ctr.planar_tests]
+        # the product's own walk (triangles: culled with boxes smaller than the reference's tripled ones) finds the same hits
+        own_ids, own_t, own = dev.trace_closest(org, d, flags=rt.FLAG_COUNT_ACTUAL)
+        assert np.array_equal(own_ids, wid) and np.array_equal(bits(own_t), bits(t)), f"bounce {bounce}: the walk's own boxes"
+        assert own.node_visits <= st.node_visits and own.planar_tests <= st.planar_tests and own.sphere_tests == st.sphere_tests
+        if kind == "triangles":
+            assert own.node_visits < 0.7 * st.node_visits and own.planar_tests < 0.5 * st.planar_tests
         hit = ids != NONE
         assert hit.any()
         org = org[hit] + d[hit] * t[hit, None]
