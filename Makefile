@@ -15,7 +15,14 @@ vpath %.cpp raytracing_amd/csrc raytracing_amd/host
 
 BIN  := bin/rtx_example
 
-all: $(LIB) $(BIN) oracle
+all: $(LIB) $(BIN) oracle build/row_regs.ok
+
+# The render kernels that read a row of rays ahead load it with inline assembly the compiler does not track; that nothing
+# reads those registers before the wait is a property of the compiler's register allocation, checked on its assembly output.
+build/row_regs.ok: raytracing_amd/csrc/rtx_kernels.hip $(HDRS) tools/check_row_regs.py
+	@mkdir -p build
+	HIPCC=$(HIPCC) python3 tools/check_row_regs.py
+	@touch $@
 
 build/%.o: % $(HDRS)
 	@mkdir -p build

@@ -47,15 +47,16 @@ KERNEL = "k_render_persistent"     # the single launch with its paths in a pool 
 KERNEL_RESIDENT = "k_render_resident"   # ... or in registers (scenes that sit in LDS whole, where paths bounce)
 
 
-def frame_kernel(names):
-    """Of the kernel names of a profile, the one that rendered the timed frames: the resident form if it ran at all (a scene's
-    first call takes the pooled form), else the pooled form's non-counting instance."""
-    names = list(names)
-    for want in (KERNEL_RESIDENT, KERNEL + "<false"):
-        hit = [k for k in names if k.replace("void ", "").replace("rtx::", "").startswith(want)]
-        if hit:
-            return hit[0]
-    return None
+def short_kernel(name):
+    return name.replace("void ", "").replace("rtx::", "").split("(")[0].strip()
+
+
+def frame_kernel(names, want):
+    """Of the kernel names of a profile, the instance of `want` (the kernel rtx_stats.kernel_form named for the timed frames)
+    that rendered them: for the pooled form its non-counting instance."""
+    prefix = want + "<false" if want == KERNEL else want
+    hit = [k for k in names if short_kernel(k).startswith(prefix)]
+    return hit[0] if hit else None
 
 # name -> (scene function kwargs -> (surfaces, camera), nominal spp, spp run by default, BVH built on: "host" | "device")
 # The 10^6-surface frames take minutes at their nominal 1000 spp: they run at 20 spp unless --spp says otherwise
@@ -152,7 +153,7 @@ def cpu_baseline(name, surfaces, cam, spp_nominal, target_s=12.0):
     return out
 
 
-def committed_traffic(name):
+def committed_traffic(name, want):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (fallback when the live passes cannot run)."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
@@ -162,58 +163,68 @@ def committed_traffic(name):
             rec = doc.get("configs", {}).get(name)
             return (rec["hbm_bytes_per_launch"], rec["rays_per_launch"], "profiles/hbm_traffic.json (committed): " + rec.get("source", "")) if rec else (None, None, None)
         recs = doc["kernels"]
-        k = frame_kernel(recs)
+        k = frame_kernel(recs, want)
         return recs[k]["hbm_bytes_per_launch"], recs[k].get("rays_per_launch"), "profiles/hbm_traffic.json (committed): " + recs[k].get("source", "")
     except (OSError, KeyError, ValueError, TypeError):
         return None, None, None
 
 
-def committed_valu_issue(name):
-    """How busy the vector ALUs were on the headline frame, from the counter passes committed under profiles/ (not measured
-    in this run): vector instructions by kind x their issue cost (profiles/r01_valu_rate.txt: f64 and 64-bit integer
-    arithmetic 4 cycles of a SIMD per wave instruction, f32 and 32-bit integer 2.2, f64 division / square root steps 16) over
-    SIMDs x kernel cycles, and the share of lanes active in them.  The f64-flop fraction cannot say this: most vector
-    instructions of the path are not f64 arithmetic (f32 box tests, the generator's integer rounds, selects, addresses)."""
-    if name != "cover_spheres":
-        return None
+# Counter passes of one frame, each a rocprofv3 run of its own (a run holds at most 8 SQ counters; FETCH_SIZE and WRITE_SIZE
+# do not fit together).  The last two price how busy the vector ALUs were.
+PMC_PASSES = [
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE"],
+    ["SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_INT64",
+     "SQ_INSTS_VALU_CVT", "GRBM_GUI_ACTIVE"],
+    ["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_SALU"],
+]
+
+
+def valu_issue(c, rays):
+    """How busy the vector ALUs were, from this run's counters of the frame's kernel (per launch): vector instructions by kind x
+    their issue cost (profiles/r01_valu_rate.txt: f64 and 64-bit integer arithmetic 4 cycles of a SIMD per wave instruction,
+    f32 and 32-bit integer 2.2, f64 division / square root steps 16) over SIMDs x kernel cycles, and the share of lanes active in
+    them.  The f64-flop fraction cannot say this: most vector instructions of the path are not f64 arithmetic (f32 box tests,
+    the generator's integer rounds, selects, addresses)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) as fh:
-            ks = json.load(fh)["kernels"]
-        r = ks[frame_kernel(ks)]
-        simd_cycles = 1024.0 * r["GRBM_GUI_ACTIVE"] / 8.0   # the counter is summed over the eight XCDs
-        f64 = r["SQ_INSTS_VALU_ADD_F64"] + r["SQ_INSTS_VALU_FMA_F64"] + r["SQ_INSTS_VALU_MUL_F64"]
-        slow = f64 + r["SQ_INSTS_VALU_INT64"] + r["SQ_INSTS_VALU_CVT"]
-        fast = r["SQ_INSTS_VALU"] - slow - r["SQ_INSTS_VALU_TRANS_F64"]
-        return {"frac": round((4.0 * slow + 16.0 * r["SQ_INSTS_VALU_TRANS_F64"] + 2.2 * fast) / simd_cycles, 3),
-                "frac_if_every_instruction_took_4_cycles": round(4.0 * r["SQ_INSTS_VALU"] / simd_cycles, 3),
-                "lanes_active": round(r["SQ_THREAD_CYCLES_VALU"] / (r["SQ_ACTIVE_INST_VALU"] * 64.0), 3),
-                "source": "profiles/r02_pmc_summary.json (committed, not of this run), issue costs from profiles/r01_valu_rate.txt"}
-    except (OSError, KeyError, ValueError, StopIteration, ZeroDivisionError, TypeError):
+        simd_cycles = 1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0   # the counter is summed over the eight XCDs
+        f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"]
+        slow = f64 + c["SQ_INSTS_VALU_INT64"] + c["SQ_INSTS_VALU_CVT"]
+        fast = c["SQ_INSTS_VALU"] - slow - c["SQ_INSTS_VALU_TRANS_F64"]
+        return {"frac": round((4.0 * slow + 16.0 * c["SQ_INSTS_VALU_TRANS_F64"] + 2.2 * fast) / simd_cycles, 3),
+                "frac_if_every_instruction_took_4_cycles": round(4.0 * c["SQ_INSTS_VALU"] / simd_cycles, 3),
+                "lanes_active": round(c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0), 3),
+                "wave_cycles_waiting": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
+                "wave_cycles_ready_but_not_issued": round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3),
+                "vector_instructions_per_ray": round(c["SQ_INSTS_VALU"] / rays, 2) if rays else None,
+                "scalar_instructions_per_ray": round(c["SQ_INSTS_SALU"] / rays, 2) if rays else None,
+                "source": "live: rocprofv3 --pmc passes of this run (per launch of the frame's kernel), issue costs from profiles/r01_valu_rate.txt"}
+    except (KeyError, ZeroDivisionError, TypeError):
         return None
 
 
-def live_traffic(args):
-    """HBM bytes of one launch of the render kernel on THIS box: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do
-    not fit in one) over a child run of this script that renders one frame.  FETCH_SIZE counts a 128-byte request as 64 bytes
-    on gfx950, so reads are doubled; both counters are in KiB.  Returns (bytes, rays of that launch, source) or Nones."""
+def live_counters(args, want):
+    """Counters of one launch of the kernel that renders the frame (`want`), on THIS box: one rocprofv3 --pmc run per entry of
+    PMC_PASSES over a child run of this script that renders one frame after one warm-up frame, as the timed run does.  Returns
+    (per-launch counter values, rays of that launch, the kernel's name as the profiler saw it, note)."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
-        return None, None, "rocprofv3 not found"
+        return {}, None, None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="rtx_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    # one warm-up frame as in the timed run: a scene's first call always takes the pooled form of the kernel
     child = ["python3", os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", args.config, "--spp", str(args.spp), "--width", str(args.width),
              "--steps", "1", "--warmup", "1"]
-    got, rays = {}, None
+    got, rays, seen, notes = {}, None, None, []
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, ctr)
-            cmd = ["timeout", "-s", "KILL", "240", rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", *child]
+        for i, ctrs in enumerate(PMC_PASSES):
+            d = os.path.join(tmp, f"pass{i}")
+            cmd = ["timeout", "-s", "KILL", "240", rocprof, "--pmc", *ctrs, "--output-format", "csv", "-d", d, "--", *child]
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd="/tmp", env=env)
             if r.returncode != 0:
-                return None, None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
+                notes.append(f"rocprofv3 --pmc {' '.join(ctrs)} failed (rc {r.returncode})")
+                continue
             for line in r.stdout.splitlines():
                 if line.startswith("{"):
                     rays = json.loads(line)["config"]["rays_per_frame"]
@@ -221,22 +232,61 @@ def live_traffic(args):
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if row["Counter_Name"] == ctr:
-                            tot = per_kernel.setdefault(row["Kernel_Name"], [0.0, set()])
-                            tot[0] += float(row["Counter_Value"])
-                            tot[1].add(row["Dispatch_Id"])
-            k = frame_kernel(per_kernel)
+                        tot = per_kernel.setdefault(row["Kernel_Name"], {}).setdefault(row["Counter_Name"], [0.0, set()])
+                        tot[0] += float(row["Counter_Value"])
+                        tot[1].add(row["Dispatch_Id"])
+            k = frame_kernel(per_kernel, want)
             if k is None:
-                return None, None, f"no {KERNEL} / {KERNEL_RESIDENT} dispatch in the {ctr} pass"
-            kernel_seen = k.replace("void ", "").replace("rtx::", "").split("(")[0]
-            got[ctr] = per_kernel[k][0] * 1024.0 / len(per_kernel[k][1])
-        return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], rays, (
-            f"live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one pass each) of {kernel_seen} over `python3 bench.py --pmc-child` on this box; "
-            f"read {2.0 * got['FETCH_SIZE'] / 1e9:.1f} GB (FETCH_SIZE x 2) + written {got['WRITE_SIZE'] / 1e9:.1f} GB")
+                notes.append(f"no {want} dispatch in the pass of {' '.join(ctrs)}")
+                continue
+            seen = short_kernel(k)
+            for c, (total, dispatches) in per_kernel[k].items():
+                got[c] = total / len(dispatches)
     except (OSError, ValueError, KeyError) as e:
-        return None, None, f"live PMC passes failed: {e}"
+        notes.append(f"live PMC passes failed: {e}")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return got, rays, seen, "; ".join(notes) or None
+
+
+def cold_frame(args):
+    """What a user of RenderRunner::run sees (src/runner.rs:24-38: ONE frame per process): a fresh process of bin/rtx_example
+    renders the configuration's frame and prints the reference's three timers; RTX_LOG_COLD=1 makes the library add the
+    host-side cost of what a process pays once (code object load, path pool, the first call's probe launch)."""
+    exe = os.path.join(ROOT, "bin", "rtx_example")
+    if args.config.startswith("synthetic") or not os.path.exists(exe):
+        return None
+    out = tempfile.NamedTemporaryFile(prefix="rtx_cold_", suffix=".ppm", dir="/tmp", delete=False)
+    out.close()
+    env = dict(os.environ, RTX_LOG_COLD="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RTX_RESIDENT"):
+        env.pop(k, None)
+    cmd = [exe, args.config, "--width", str(args.width), "--spp", str(args.spp), "--seed", str(SEED), "-o", out.name]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(["timeout", "-k", "10", "300", *cmd], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=env)
+    finally:
+        wall = time.perf_counter() - t0
+        try:
+            os.unlink(out.name)
+        except OSError:
+            pass
+    if r.returncode != 0:
+        return {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+    res = {"command": "RTX_LOG_COLD=1 bin/rtx_example " + " ".join(cmd[1:-2]) + " -o <file>", "process_wall_s": round(wall, 4), "once_per_process_ms": {}}
+    for line in r.stderr.splitlines():
+        line = line.strip()
+        for key, name in (("Total runtime:", "total_runtime_s"), ("BVH construction:", "bvh_construction_s"), ("Rendering:", "rendering_s")):
+            if line.startswith(key):
+                res[name] = float(line.split(":")[1].strip().rstrip("s"))
+        if line.startswith("rays:") and "device:" in line:
+            res["device_ms"] = float(line.split("device:")[1].split("ms")[0])
+        if line.startswith("rtx cold:"):
+            what, ms = line[len("rtx cold:"):].rsplit(" ", 2)[0].strip(), float(line.rsplit(" ", 2)[1])
+            res["once_per_process_ms"][what] = round(res["once_per_process_ms"].get(what, 0.0) + ms, 3)
+    res["note"] = ("the reference's timers: total = BVH construction + rendering; rendering spans scene upload, the render call (device_ms of it "
+                   "on the GPU), the P3 text made on the device, its copy to the host and the write of the file")
+    return res
 
 
 def free_port():
@@ -245,19 +295,64 @@ def free_port():
         return s.getsockname()[1]
 
 
-def spawn_ranks(n, json_out):
+def spawn_ranks(n, json_out, grace_s=120.0):
     """`python bench.py --gpus N` typed as is: N fresh ranks of this script, one per GPU.  Runs before this process has
-    made any GPU call (it never makes one); prints what rank 0 printed and returns the worst exit status."""
+    made any GPU call (it never makes one).  All ranks are watched: when one exits with an error the others are ended (they
+    would wait for it in a collective until some outer limit), its last lines of stderr are shown, and the status is non-zero
+    within seconds; ranks that outlive the first clean exit by more than `grace_s` are ended as well.  Prints what rank 0
+    printed and returns the worst exit status."""
     port = free_port()
-    procs = []
+    procs, logs = [], []
+    argv = [a for a in sys.argv[1:] if a != "--force-spawn"]
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *[a for a in sys.argv[1:] if a != "--force-spawn"]], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, abs(p.wait()))
+        log = tempfile.TemporaryFile(mode="w+", prefix=f"rtx_rank{r}_", dir="/tmp")
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=log, text=True))
+
+    def tail(r, lines=25):
+        logs[r].seek(0)
+        return "".join(logs[r].readlines()[-lines:])
+
+    def end_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    rc, first_exit = 0, None
+    while any(p.poll() is None for p in procs):
+        failed = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if failed:
+            r = failed[0]
+            rc = abs(procs[r].returncode) or 1
+            print(f"bench.py: rank {r} of {n} exited with status {procs[r].returncode}; ending the other ranks. Its last lines:\n{tail(r)}", file=sys.stderr, flush=True)
+            end_all()
+            break
+        if first_exit is None and any(p.poll() == 0 for p in procs):
+            first_exit = time.time()
+        if first_exit is not None and time.time() - first_exit > grace_s:
+            late = [r for r, p in enumerate(procs) if p.poll() is None]
+            print(f"bench.py: ranks {late} still running {grace_s:.0f} s after the first rank finished; ending them. Rank {late[0]}'s last lines:\n{tail(late[0])}",
+                  file=sys.stderr, flush=True)
+            rc = 1
+            end_all()
+            break
+        time.sleep(0.05)
+    for r, p in enumerate(procs):
+        if p.returncode not in (None, 0) and rc == 0:
+            rc = abs(p.returncode) or 1
+            print(f"bench.py: rank {r} of {n} exited with status {p.returncode}. Its last lines:\n{tail(r)}", file=sys.stderr, flush=True)
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    if rc == 0:
+        sys.stderr.write(tail(0, 1000))   # what rank 0 had to say (RCCL's banner and the like)
     json_out.write(out)
     json_out.flush()
     return rc
@@ -272,7 +367,9 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel (default: the configuration's own)")
     ap.add_argument("--width", type=int, default=0, help="image width (default: the configuration's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 counter passes behind roofline.traffic")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes behind roofline.traffic and roofline.valu_issue")
+    ap.add_argument("--no-image-check", action="store_true", help="do not render the frame once more in the other form of the kernel")
+    ap.add_argument("--no-cold-frame", action="store_true", help="do not time a fresh process of bin/rtx_example")
     ap.add_argument("--single-process", action="store_true", help="N GPUs from one process through rtx_multi_render")
     ap.add_argument("--time-kernels", action="store_true", help="round-loop path with per-kernel HIP event timing (diagnostic)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # one bare frame under rocprofv3
@@ -318,14 +415,18 @@ def main():
     nval = W * H * 3
     stream = torch.cuda.current_stream().cuda_stream
 
+    per_rank = None   # N > 1: what every rank did, for the line
+    reduce_events = []
     if args.single_process:
         multi = rt.MultiScene(bvh, args.gpus)   # scene on every device + ncclCommInitAll: outside the timed region
         ranks_seen = None
+        multi_stats = []
 
         def step(flags=0):
             nonlocal ranks_seen
             _, ms = multi.render(icam, SEED, flags, to_host=False)
             ranks_seen = ms.collective_ranks
+            multi_stats.append(ms)
             st = rt.Stats()
             st.rays, st.paths, st.ms_total = ms.rays, ms.paths, max(ms.ms_device[: args.gpus])
             return st
@@ -340,7 +441,12 @@ def main():
         def step(flags=0):
             acc.zero_()
             st = scene.render_accumulate(icam, SEED, begin, count, acc.data_ptr(), stream, flags) if count else rt.Stats()
-            reduce_accum(acc, world)
+            if world > 1:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                reduce_accum(acc, world)
+                e1.record()
+                reduce_events.append((e0, e1))
             if rank == 0:
                 rt.scale(acc.data_ptr(), nval, icam.pixel_samples_scale, image.data_ptr(), stream)
             return st
@@ -355,6 +461,9 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    reduce_events.clear()
+    if args.single_process:
+        multi_stats.clear()
     barrier()
     t0 = time.perf_counter()
     stats = [step(rt.FLAG_TIME_KERNELS if args.time_kernels else 0) for _ in range(args.steps)]
@@ -364,8 +473,23 @@ def main():
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     work = torch.tensor([sum(s.rays for s in stats), sum(s.paths for s in stats)], dtype=torch.float64, device=dev)
     if world > 1:
+        # what each rank did: its share of the samples, the device time of its render call and of the reduce as it saw it
+        mine = torch.tensor([float(count), sum(s.ms_total for s in stats) / args.steps,
+                             sum(a.elapsed_time(b) for a, b in reduce_events) / max(len(reduce_events), 1), elapsed * 1e3 / args.steps],
+                            dtype=torch.float64, device=dev)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        per_rank = {"spp_count": [int(v[0].item()) for v in everyone], "ms_render": [round(v[1].item(), 3) for v in everyone],
+                    "ms_reduce": [round(v[2].item(), 3) for v in everyone], "ms_step_wall": [round(v[3].item(), 3) for v in everyone]}
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(work, op=dist.ReduceOp.SUM)
+    elif args.single_process and multi_stats:
+        n = args.gpus
+        per_rank = {"spp_count": [int(multi_stats[-1].spp_count[g]) for g in range(n)],
+                    "ms_render": [round(sum(m.ms_device[g] for m in multi_stats) / len(multi_stats), 3) for g in range(n)],
+                    "ms_render_host_wall": [round(sum(m.ms_render[g] for m in multi_stats) / len(multi_stats), 3) for g in range(n)],
+                    "ms_reduce": round(sum(m.ms_reduce for m in multi_stats) / len(multi_stats), 3),
+                    "ms_frame": round(sum(m.ms_frame for m in multi_stats) / len(multi_stats), 3)}
     elapsed = float(t.item())
     rays_per_step = work[0].item() / args.steps
     paths_per_step = work[1].item() / args.steps
@@ -403,9 +527,15 @@ def main():
                 "bvh_build_ms": round(bvh_ms, 2),
             },
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        if scene is not None and stats:
+            out["config"]["kernel"] = rt.FORM_KERNEL.get(stats[-1].kernel_form)
         if args.pmc_child or scene is None:   # a bare frame for the counter passes / the single-process form: no counting pass
             print(json.dumps(out), file=json_out, flush=True)
         else:
+            if not args.no_image_check and world == 1:
+                out["image_check"] = image_check(rt, torch, scene, icam, stats[-1], begin, count, acc, stream)
             out["roofline"] = roofline(rt, scene, bvh.n_nodes, icam, stats, begin, count, acc, stream, args)
             if args.time_kernels:   # round-loop path: summed launch durations per kernel
                 out["roofline"]["kernel_time_share"] = {"traverse_ms": round(sum(s.ms_traverse for s in stats) / args.steps, 2),
@@ -414,6 +544,8 @@ def main():
             if not args.no_cpu_baseline and world == 1:
                 out["cpu_baseline"] = cpu_baseline(args.config, surfaces, cam, cfg["spp"])
                 out["speedup_vs_cpu_baseline"] = round(mrays / out["cpu_baseline"]["value"], 1)
+            if not args.no_cold_frame and world == 1:
+                out["cold_frame"] = cold_frame(args)
             print(json.dumps(out), file=json_out, flush=True)
 
     if dist.is_initialized():
@@ -421,23 +553,57 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(rt, scene, n_nodes, icam, stats, begin, count, acc, stream, args):
-    """Roofline of the one kernel a frame is (k_render_persistent, one launch per step), from this rank's launches.
+def image_check(rt, torch, scene, icam, last, begin, count, acc, stream):
+    """The frame of the last timed step (its radiance sums are still in `acc`) against one more render of the same samples by
+    ANOTHER implementation of the sample loop: the other form of the single launch where the scene allows both (paths resident
+    in registers <-> paths in a pool), else the round loop of separate generate / traverse / shade launches.  Every (pixel,
+    sample) has its own random stream, so the two must agree up to the order of the f64 additions and trace the same rays."""
+    saved = {k: os.environ.get(k) for k in ("RTX_RESIDENT", "RTX_PERSISTENT")}
+    other = torch.zeros_like(acc)
+    try:
+        os.environ["RTX_RESIDENT"] = "0" if last.kernel_form == rt.FORM_RESIDENT else "1"
+        st = scene.render_accumulate(icam, SEED, begin, count, other.data_ptr(), stream)
+        if st.kernel_form == last.kernel_form:   # the scene has one form of the single launch only
+            os.environ["RTX_PERSISTENT"] = "0"
+            other.zero_()
+            st = scene.render_accumulate(icam, SEED, begin, count, other.data_ptr(), stream)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    scale = torch.maximum(acc.abs(), other.abs())
+    rel = torch.where(scale > 0, (acc - other).abs() / scale.clamp_min(1e-300), torch.zeros_like(acc))
+    return {"timed_form": rt.FORM_KERNEL.get(last.kernel_form), "other_form": rt.FORM_KERNEL.get(st.kernel_form),
+            "max_rel_diff": float(rel.max().item()), "rays_equal": bool(st.rays == last.rays), "rays": int(st.rays),
+            "paths_equal": bool(st.paths == last.paths), "pixels_that_differ_by_more_than_1e-12": int((rel > 1e-12).any(dim=-1).sum().item()),
+            "other_form_ms": round(st.ms_total, 3)}
 
-    Work per ray is algorithmic: Nv box tests, Ns sphere tests, Np planar tests per ray from a counting pass of the same
-    kernel (equal to the CPU oracle's counters), priced at
+
+def roofline(rt, scene, n_nodes, icam, stats, begin, count, acc, stream, args):
+    """Roofline of the one kernel a frame is (one launch per step: rtx_stats.kernel_form says which), from this rank's launches.
+
+    Work per ray is algorithmic: Nv box tests, Ns sphere tests, Np planar tests per ray of the walk that runs, from a
+    counting pass of the same kernel (RTX_FLAG_COUNT_ACTUAL), priced at
         flops = 37 Nv + 30 Ns + 57 Np + 60
         bytes = 56 Nv + 32 Ns + 128 Np (nodes, spheres, planars) + 40 (material) + 160 (ray state, read + write) + 12 (hit record)
                 + 12 per path (accumulation).
-    Launch time is the HIP-event time of the launch on its stream (rtx_stats.ms_total).
+    The reference's own walk makes more tests on scenes of quads and triangles (it culls with boxes padded to three times
+    the surface's extent, src/aabb.rs:78-87): its counts (RTX_FLAG_COUNT_WORK, equal to the CPU oracle's) are reported beside
+    (`reference_walk`), and `achieved` is priced on the tests actually made, so that a walk that skips work is not credited
+    with it.  Launch time is the HIP-event time of the launch on its stream (rtx_stats.ms_total).
     Which bound applies depends on where the tree lives.  Scenes whose node records sit in LDS (every example scene)
     are bound by f64 vector arithmetic, latency and divergence: `frac` is the f64-VALU fraction, and only the ray state, hit
     records, material records and accumulation of the byte formula can reach HBM (`hbm.algorithmic`).  The 10^6-surface scenes
     walk their tree from global memory: `frac` is the byte formula with the node record this design reads (16 or 32 B per
     visit instead of the 56 B of an SoA f64 node: 48 B box + two links) over the HBM peak; the counters see more (`hbm.measured_over_algorithmic`): every
     16-byte record read that misses L2 moves a whole line."""
-    cnt = scene.render_accumulate(icam, SEED, begin, min(count, 2), acc.data_ptr(), stream, rt.FLAG_COUNT_WORK)
+    cnt = scene.render_accumulate(icam, SEED, begin, min(count, 2), acc.data_ptr(), stream, rt.FLAG_COUNT_ACTUAL)
+    ref = scene.render_accumulate(icam, SEED, begin, min(count, 2), acc.data_ptr(), stream, rt.FLAG_COUNT_WORK)
     nv, ns, npl = cnt.node_visits / cnt.rays, cnt.sphere_tests / cnt.rays, cnt.planar_tests / cnt.rays
+    form = stats[-1].kernel_form
+    kernel = {rt.FORM_RESIDENT: KERNEL_RESIDENT, rt.FORM_POOLED: KERNEL}.get(form, "k_traverse_f32")
     rank_rays = sum(s.rays for s in stats)
     rank_paths = sum(s.paths for s in stats)
     launches = len(stats)
@@ -460,11 +626,19 @@ def roofline(rt, scene, n_nodes, icam, stats, begin, count, acc, stream, args):
         gbs_all = (scene_bytes_per_ray + state_bytes_per_ray) * rays_per_launch / avg_launch_s / 1e9
 
     traffic = t_rays = src = None
-    if not args.no_pmc and args.gpus == 1:
-        traffic, t_rays, src = live_traffic(args)
+    counters, seen = {}, None
+    if not args.no_pmc and args.gpus == 1 and form in (rt.FORM_RESIDENT, rt.FORM_POOLED):
+        counters, t_rays, seen, note = live_counters(args, kernel)
+        if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:   # both in KiB; FETCH_SIZE tallies a 128-byte request as 64 bytes on gfx950
+            rd, wr = 2.0 * counters["FETCH_SIZE"] * 1024.0, counters["WRITE_SIZE"] * 1024.0
+            traffic = rd + wr
+            src = (f"live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one pass each) of {seen} over `python3 bench.py --pmc-child` on this box; "
+                   f"read {rd / 1e9:.1f} GB (FETCH_SIZE x 2) + written {wr / 1e9:.1f} GB")
+        else:
+            src = note
     if traffic is None:
         live_note = src
-        traffic, t_rays, src = committed_traffic(args.config)
+        traffic, t_rays, src = committed_traffic(args.config, kernel)
         if live_note and src:
             src += f" [{live_note}]"
     if traffic is not None and t_rays:   # the counted launch may have traced a few more or fewer rays (another seed or spp): scale per ray
@@ -480,7 +654,8 @@ def roofline(rt, scene, n_nodes, icam, stats, begin, count, acc, stream, args):
         "measured_over_algorithmic": round(traffic / rays_per_launch / (state_bytes_per_ray if tree_on_chip else scene_bytes_per_ray + state_bytes_per_ray), 3) if traffic else None,
     }
     common = {
-        "kernel": KERNEL_RESIDENT if KERNEL_RESIDENT in (src or "") else KERNEL,
+        "kernel": kernel,
+        "kernel_seen_by_profiler": seen,
         "traffic": round(traffic, 1) if traffic else None,
         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE)",
         "traffic_source": src,
@@ -491,16 +666,21 @@ def roofline(rt, scene, n_nodes, icam, stats, begin, count, acc, stream, args):
         "sphere_tests_per_ray": round(ns, 3),
         "planar_tests_per_ray": round(npl, 3),
         "flops_per_ray": round(flops_per_ray, 1),
+        "reference_walk": {"nodes_per_ray": round(ref.node_visits / ref.rays, 3), "sphere_tests_per_ray": round(ref.sphere_tests / ref.rays, 3),
+                           "planar_tests_per_ray": round(ref.planar_tests / ref.rays, 3),
+                           "flops_per_ray": round(37.0 * ref.node_visits / ref.rays + 30.0 * ref.sphere_tests / ref.rays + 57.0 * ref.planar_tests / ref.rays + 60.0, 1),
+                           "note": "box and surface tests of the reference's BVH::hit on the same rays (RTX_FLAG_COUNT_WORK; equal to the CPU oracle's counters); "
+                                   "nodes_per_ray etc. above are the tests this walk makes, and `achieved` is priced on those"},
         "box_tests_left_to_f64_tiers": cnt.box_fallbacks / max(cnt.node_visits, 1),
         "rounds_of_busiest_wave": int(max(s.iterations for s in stats)),
         "hbm": hbm,
         "valu_f64": {"achieved_tflops": round(tf, 3), "peak_tflops": FP64_VECTOR_PEAK_TF, "frac": round(tf / FP64_VECTOR_PEAK_TF, 4)},
-        "valu_issue": committed_valu_issue(args.config),
+        "valu_issue": valu_issue(counters, t_rays) if counters else None,
         "on_chip_note": f"{scene_bytes_per_ray:.0f} B/ray of the byte formula are node and surface records "
                         + ("served from LDS (the tree and the surface tables are copied there once per block): not HBM traffic"
                            if tree_on_chip else "read from global memory (the tree is far larger than LDS and L2)")
                         + ("; in the resident form of the kernel the paths stay in registers from bounce to bounce, so the formula's ray state and hit "
-                           "records do not move either: what is measured is the image's atomic adds" if KERNEL_RESIDENT in (src or "") else ""),
+                           "records do not move either: what is measured is the image's atomic adds" if form == rt.FORM_RESIDENT else ""),
     }
     if tree_on_chip:
         return dict({"bound": "valu_f64", "achieved": round(tf, 3), "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",

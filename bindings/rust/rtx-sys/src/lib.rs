@@ -42,6 +42,7 @@ pub const RTX_FLAG_EXACT_DIVIDE: u32 = 4;
 pub const RTX_FLAG_F64_FILTER: u32 = 8;
 pub const RTX_FLAG_NO_LDS: u32 = 16;
 pub const RTX_FLAG_NO_WAIT: u32 = 32;
+pub const RTX_FLAG_COUNT_ACTUAL: u32 = 64;
 
 /// A built BVH, flattened: the pre-order node array of `BVH { tree }` (src/bvh/mod.rs:51-73) with each enum
 /// field in its own table.  Vector tables are three rows: x[0..n), y[0..n), z[0..n).
@@ -103,7 +104,15 @@ pub struct rtx_stats {
     pub ms_traverse: f64,
     pub ms_shade: f64,
     pub ms_generate: f64,
+    pub kernel_form: u32,
+    pub _reserved: u32,
 }
+
+/// `rtx_stats.kernel_form`
+pub const RTX_FORM_NONE: u32 = 0;
+pub const RTX_FORM_ROUND_LOOP: u32 = 1;
+pub const RTX_FORM_POOLED: u32 = 2;
+pub const RTX_FORM_RESIDENT: u32 = 3;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]

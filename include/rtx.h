@@ -108,7 +108,17 @@ typedef struct rtx_stats {
     double   ms_traverse;    /* summed duration of the traverse kernel launches (0 unless RTX_FLAG_TIME_KERNELS). */
     double   ms_shade;       /* A render call runs several independent lanes side by side on their own streams, */
     double   ms_generate;    /* so kernels of different lanes overlap and these sums can exceed ms_total.       */
+    uint32_t kernel_form;    /* which kernels a render call ran: enum rtx_kernel_form (of the call's last launch) */
+    uint32_t _reserved;
 } rtx_stats;
+
+/* rtx_stats.kernel_form */
+enum rtx_kernel_form {
+    RTX_FORM_NONE = 0,       /* nothing was launched (or not a render call) */
+    RTX_FORM_ROUND_LOOP = 1, /* k_generate / k_traverse* / k_shade launches per round */
+    RTX_FORM_POOLED = 2,     /* one launch, paths in a pool in HBM between bounces (k_render_persistent) */
+    RTX_FORM_RESIDENT = 3    /* one launch, paths in registers from bounce to bounce (k_render_resident) */
+};
 
 typedef struct rtx_scene rtx_scene;
 

@@ -34,6 +34,8 @@ FLAG_F64_FILTER = 8
 FLAG_NO_LDS = 16
 FLAG_NO_WAIT = 32
 FLAG_COUNT_ACTUAL = 64
+FORM_NONE, FORM_ROUND_LOOP, FORM_POOLED, FORM_RESIDENT = 0, 1, 2, 3
+FORM_KERNEL = {FORM_ROUND_LOOP: "k_generate + k_traverse_f32 + k_shade", FORM_POOLED: "k_render_persistent", FORM_RESIDENT: "k_render_resident"}
 TRACE_DEVICE_MAX_RAYS = 1 << 20
 
 BISECT, MIDPOINT, SAH_EQUAL_SIZE, SAH_PER_SURFACE = 0, 1, 2, 3
@@ -88,7 +90,7 @@ class Stats(C.Structure):  # rtx_stats
     _fields_ = [
         ("rays", C.c_uint64), ("paths", C.c_uint64), ("node_visits", C.c_uint64), ("sphere_tests", C.c_uint64),
         ("planar_tests", C.c_uint64), ("box_fallbacks", C.c_uint64), ("iterations", C.c_uint64), ("ms_total", C.c_double), ("ms_traverse", C.c_double),
-        ("ms_shade", C.c_double), ("ms_generate", C.c_double),
+        ("ms_shade", C.c_double), ("ms_generate", C.c_double), ("kernel_form", C.c_uint32), ("_reserved", C.c_uint32),
     ]
 
     def as_dict(self):

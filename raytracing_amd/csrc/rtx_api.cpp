@@ -29,6 +29,11 @@ namespace rtx {
 
 int api_fail(int code, const std::string& msg) { return fail(code, msg); }
 
+bool cold_log_on() {
+    static const bool on = env_u32("RTX_LOG_COLD", 0, true) != 0u;
+    return on;
+}
+
 uint32_t env_u32(const char* name, uint32_t dflt, bool zero_ok) {
     const char* v = std::getenv(name);
     if (!v || !*v) return dflt;
@@ -76,9 +81,15 @@ int PathPool::ensure_counters(uint32_t n_sub) {
     counters_n = n_sub;
     return RTX_OK;
 }
-int PathPool::ensure_capacity(size_t n) {
+int PathPool::ensure_ctl() {
     HIP_TRY(ctl.resize(8));   // the records behind the first are scratch for instrumented debug builds
+    return RTX_OK;
+}
+int PathPool::ensure_capacity(size_t n) {
+    int rc = ensure_ctl();
+    if (rc != RTX_OK) return rc;
     if (n <= capacity) return RTX_OK;
+    ColdTimer cold("path pool allocation");
     // Both new buffers are allocated before either old one is let go: if one allocation fails the pool is
     // exactly as it was (RTX_ERR_OOM is recoverable), never half replaced with `capacity` describing freed memory.
     // The old buffers are released first only when they are all that stands in the way (second attempt).
@@ -482,6 +493,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
         }
     }
 
+    ColdTimer cold_upload("scene upload (first HIP calls of a process included)");
     rtx_scene* sc = new rtx_scene();
     auto bail = [&](int code) {
         delete sc;
@@ -491,6 +503,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     if (e != hipSuccess) return bail(fail(RTX_ERR_NO_DEVICE, std::string("hipGetDevice: ") + hipGetErrorString(e)));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, sc->device) == hipSuccess && prop.multiProcessorCount > 0) sc->n_cus = (uint32_t)prop.multiProcessorCount;
+    sc->trace_max_waves = sc->n_cus * env_u32("RTX_WAVES_PER_CU", 20);
 
 #define UP(buf, vec)                                                                                                   \
     do {                                                                                                               \
@@ -592,10 +605,9 @@ int rtx_trace_closest(rtx_scene* sc, const double* org, const double* dir, uint6
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (n == 0) return RTX_OK;
     HIP_TRY(hipSetDevice(sc->device));
-    const uint32_t max_waves = sc->n_cus * env_u32("RTX_WAVES_PER_CU", 20);
     uint32_t n_sub;
     uint64_t sub_capacity;
-    pool_geometry(n, max_waves, &n_sub, &sub_capacity);
+    pool_geometry(n, sc->trace_max_waves, &n_sub, &sub_capacity);
     if (sub_capacity * n_sub > 0xFFFFFFFFull) return fail(RTX_ERR_BAD_ARG, "rtx_trace_closest: batch too large");
     PathPool* pp = sc->lane(0);
     int rc = pp->ensure_capacity((size_t)n);
@@ -733,9 +745,12 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         // other samples follow in the form that suits: the reference renders one frame per process, so its first call is its only one.
         if (sc->rays_per_path == 0.0 && !no_wait && !(force_form && *force_form) && !counting(flags) && !(flags & RTX_FLAG_NO_LDS) &&
             !sc->d.batch_undecided && spp_count >= 8u && persistent_lds_bytes(sc->d, 3u, true) <= wide_limit &&
-            resident_waves_per_cu(sc->d, 16u) != 0u && env_u32("RTX_PROBE_FIRST_CALL", 1, true) != 0u) {
+            sc->occupancy(1u, 16u, true, [&] { return resident_waves_per_cu(sc->d, 16u); }) != 0u && env_u32("RTX_PROBE_FIRST_CALL", 1, true) != 0u) {
             rtx_stats first{}, rest{};
-            rc = rtx_render_accumulate(sc, cam, seed, spp_begin, 1u, flags, d_accum, stream, &first);
+            {
+                ColdTimer cold("first-sample probe call (pooled form, 1 spp)");
+                rc = rtx_render_accumulate(sc, cam, seed, spp_begin, 1u, flags, d_accum, stream, &first);
+            }
             if (rc != RTX_OK) return rc;
             if (sc->rays_per_path == 0.0) sc->rays_per_path = 1.0;   // (cannot be: a path is at least one ray)
             rc = rtx_render_accumulate(sc, cam, seed, spp_begin + 1u, spp_count - 1u, flags, d_accum, stream, &rest);
@@ -753,35 +768,40 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
             }
             return RTX_OK;
         }
+        const bool recs_allowed = env_u32("RTX_LDS_RECS", 1, true) != 0u;
         if (mode <= 1u && !(flags & RTX_FLAG_NO_LDS)) {
             // What does not fit in LDS five times per CU may fit once: one 1024-thread block per CU then holds the tree, and the surface
             // tables if there is room, for sixteen waves (RTX_LDS_WIDE_BYTES: the most LDS such a block may take, 0 = never).
             if (persistent_lds_bytes(sc->d, 3u, false) <= wide_limit) mode = 3u;
             else if (mode == 0u && persistent_lds_bytes(sc->d, 4u, false) <= wide_limit) mode = 4u;
-            if (mode == 3u) lds_recs = persistent_lds_bytes(sc->d, 3u, true) <= wide_limit;
-        } else if (mode == 2u && want_resident && persistent_lds_bytes(sc->d, 3u, true) <= wide_limit) {
-            mode = 3u;   // a small scene: the resident form exists as one block per CU only
-            lds_recs = true;
+            if (mode == 3u) lds_recs = recs_allowed && persistent_lds_bytes(sc->d, 3u, true) <= wide_limit;
         }
-        if (mode == 2u) lds_recs = persistent_lds_bytes(sc->d, 2u, true) <= env_u32("RTX_LDS_SCENE_BYTES", 32u * 1024u);
-        if (env_u32("RTX_LDS_RECS", 1, true) == 0u) lds_recs = false;
-        // (its waves stage the primary rays they make in LDS, 64 at a time where there is room, else 48, 32 or 16)
+        // The resident form exists as one block per CU with the tree, the surface tables and the shade records in LDS; its waves
+        // stage the primary rays they make in LDS as well, 64 at a time where there is room, else 48, 32 or 16.  A small scene
+        // (mode 2) moves to that block shape only once the form is known to fit; otherwise it stays in its five blocks per CU.
         uint32_t resident_waves = 0u, resident_batch = 0u;
-        if (mode == 3u && lds_recs && want_resident)
+        if (want_resident && recs_allowed && ((mode == 3u && lds_recs) || (mode == 2u && persistent_lds_bytes(sc->d, 3u, true) <= wide_limit)))
             for (uint32_t b : {64u, 48u, 32u, 16u}) {
-                resident_waves = resident_waves_per_cu(sc->d, b);
+                resident_waves = sc->occupancy(1u, b, true, [&] { return resident_waves_per_cu(sc->d, b); });
                 resident_batch = b;
                 if (resident_waves) break;
             }
         const bool resident = resident_waves != 0u;
-        const uint32_t waves = sc->n_cus * (resident ? resident_waves : persistent_waves_per_cu(sc->d, mode, lds_recs));   // exactly what is resident at once
+        if (resident) {
+            mode = 3u;
+            lds_recs = true;
+        } else if (mode == 2u) {
+            lds_recs = recs_allowed && persistent_lds_bytes(sc->d, 2u, true) <= env_u32("RTX_LDS_SCENE_BYTES", 32u * 1024u);
+        }
+        const uint32_t waves = sc->n_cus * (resident ? resident_waves   // exactly what is resident at once
+                                                     : sc->occupancy(0u, mode, lds_recs, [&] { return persistent_waves_per_cu(sc->d, mode, lds_recs); }));
         const uint64_t want = env_u32("RTX_POOL_SLOTS", 1u << 22);   // ~800 slots per wave: a round ends with a drain, so long rounds pay, but state that stays in the last-level cache pays too
         const uint64_t need = total < want ? total : want;
         uint32_t n_sub;
         uint64_t per_sub;
         pool_geometry(need, waves, &n_sub, &per_sub);
         if (per_sub * n_sub > 0xFFFFFFFFull) return fail(RTX_ERR_BAD_ARG, "rtx_render_accumulate: pool larger than 2^32-1 slots");
-        rc = pp->ensure_capacity((size_t)per_sub * n_sub);
+        rc = resident ? pp->ensure_ctl() : pp->ensure_capacity((size_t)per_sub * n_sub);   // (the resident form keeps no path in memory)
         if (rc != RTX_OK) return rc;
         HIP_TRY(pp->params.resize(1));
         uint32_t slot = 0;
@@ -838,6 +858,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
             stats->planar_tests = back.planar_tests;
             stats->box_fallbacks = back.box_fallbacks;
             stats->iterations = back.rounds_max;
+            stats->kernel_form = resident ? RTX_FORM_RESIDENT : RTX_FORM_POOLED;
         }
 #ifdef RTX_PROFILE_PHASES
         {
@@ -1001,6 +1022,7 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
         (void)hipEventElapsedTime(&ms, sc->ev0, sc->ev1);
         stats->ms_total = ms;
         stats->paths = total;
+        stats->kernel_form = RTX_FORM_ROUND_LOOP;
         for (LaneRun& L : lanes) {
             stats->iterations += L.iters;
             const std::vector<hipEvent_t>& evs = L.pp->kernel_events;
@@ -1034,8 +1056,19 @@ int rtx_ppm_text(const double* d_rgb, uint32_t width, uint32_t height, char* out
     if (width == 0 || height == 0) return fail(RTX_ERR_BAD_ARG, "rtx_ppm_text: empty image");
     if ((uint64_t)width * height > (1ull << 28)) return fail(RTX_ERR_BAD_ARG, "rtx_ppm_text: more than 2^28 pixels");
     if (rtx_device_count() <= 0) return fail(RTX_ERR_NO_DEVICE, "rtx_ppm_text: no HIP device");
+    // The image may live on another device than the caller's current one (rtx_multi_image is device 0's memory whatever the
+    // caller's device is): the work runs where the image is, and the caller's device is restored.
+    int current = 0, prior = -1;
+    hipPointerAttribute_t attr{};
+    if (hipGetDevice(&current) == hipSuccess && hipPointerGetAttributes(&attr, d_rgb) == hipSuccess && attr.type == hipMemoryTypeDevice &&
+        attr.device != current) {
+        HIP_TRY(hipSetDevice(attr.device));
+        prior = current;
+    }
+    (void)hipGetLastError();   // (a pointer the runtime does not know leaves an error behind; the kernels will report a bad one)
     std::string msg;
     const int code = ppm_text_device(d_rgb, width, height, out_text, capacity, out_len, (hipStream_t)stream, msg);
+    if (prior >= 0) (void)hipSetDevice(prior);
     return code == RTX_OK ? RTX_OK : fail(code, msg);
 }
 

@@ -4,6 +4,9 @@
 #include "../../include/rtx.h"
 #include "rtx_kernels.h"
 
+#include <chrono>
+#include <cstdio>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -55,6 +58,19 @@ struct DevBuf {
 // Sizes and counts from the environment: 0 is not a valid value and yields the default; switches pass zero_ok.
 uint32_t env_u32(const char* name, uint32_t dflt, bool zero_ok = false);
 
+// RTX_LOG_COLD=1: the host-side cost of what a process pays once (code object load, pool allocation, the first call's
+// probe launch) goes to stderr, one "rtx cold: <what> <ms> ms" line each; bench.py's cold_frame reads them.
+bool cold_log_on();
+struct ColdTimer {
+    std::chrono::steady_clock::time_point t0;
+    const char* what;
+    explicit ColdTimer(const char* w) : t0(std::chrono::steady_clock::now()), what(w) {}
+    ~ColdTimer() {
+        if (cold_log_on())
+            std::fprintf(stderr, "rtx cold: %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
 // One lane of the render loop: a path pool (two ping-pong state buffers and
 // the hit records), its control block and per-sub-pool counters, and the
 // stream its rounds run on.  Lanes are independent; a render call runs
@@ -89,6 +105,7 @@ struct PathPool {
     int ensure_host_side();
     int ensure_counters(uint32_t n_sub);
     int ensure_capacity(size_t n);
+    int ensure_ctl();   // the control block alone (the resident render keeps no path in memory)
 };
 
 // Splits `need` slots into one sub-pool per wave of the launch grid: at most
@@ -102,6 +119,7 @@ void pool_geometry(uint64_t need, uint32_t max_waves, uint32_t* n_sub, uint64_t*
 struct rtx_scene {
     int device = 0;
     uint32_t n_cus = 256;
+    uint32_t trace_max_waves = 5120;   // most waves a closest-hit batch is cut into (n_cus x RTX_WAVES_PER_CU, read when the scene is created)
     rtx::DScene d{};
     rtx::DevBuf<rtx::DNode> nodes;
     rtx::DevBuf<rtx::DSphere> spheres;
@@ -121,6 +139,17 @@ struct rtx_scene {
     // Lanes of the render loop, created on first use and kept.  Lane 0 also serves rtx_trace_closest.
     std::vector<std::unique_ptr<rtx::PathPool>> lanes;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // Answers of the occupancy queries behind a render call's launch shape (kernel form, LDS mode or staged batch, shade
+    // records in LDS or not), asked once per scene: a query costs tens of microseconds and a call made up to six.
+    std::map<uint32_t, uint32_t> occupancy_cache;
+    template <class F>
+    uint32_t occupancy(uint32_t form, uint32_t shape, bool recs, F query) {
+        const uint32_t key = (form << 16) | (shape << 1) | (recs ? 1u : 0u);
+        auto it = occupancy_cache.find(key);
+        if (it == occupancy_cache.end()) it = occupancy_cache.emplace(key, query()).first;
+        return it->second;
+    }
 
     rtx::PathPool* lane(size_t j) {
         while (lanes.size() <= j) lanes.emplace_back(new rtx::PathPool());

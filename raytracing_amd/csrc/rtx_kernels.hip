@@ -1006,6 +1006,11 @@ __device__ __noinline__ double2 sphere_uv(double px, double py, double pz) {
 // after its loads (lanes that have nothing to add or store are masked out, the instruction is still issued and counted), so the
 // wait for the row's loads is `vmcnt(ROW_TAIL_OPS)` and leaves the stores in flight.  The compiler does not know of these loads:
 // their results may only be used after row_wait().
+// This rests on two properties: (1) a vector memory instruction issued with an empty EXEC mask (a row without survivors, or
+// without anything to add) still counts up vmcnt and counts it down again in order -- the ISA's counters are per instruction
+// issued, not per lane served; a GPU test renders frames whose rows are all of that kind -- and (2) the compiler never reads,
+// copies or spills the destination registers of a row in flight, which tools/check_row_regs.py verifies on the compiler's
+// assembly output as a step of the build.
 constexpr int ROW_TAIL_OPS = 16;   // 3 atomics + 13 stores
 struct RowAhead {
     uint32_t handle, pixel, sample, draw, depth;

@@ -12,7 +12,11 @@ using namespace rtx;
 
 namespace {
 
+#ifdef RTX_SCRATCH_PROBE_RAYS   // measurement builds only: what does the size of the array add to the load of the code object?
+constexpr uint64_t MAX_RAYS = RTX_SCRATCH_PROBE_RAYS;
+#else
 constexpr uint64_t MAX_RAYS = RTX_TRACE_DEVICE_MAX_RAYS;
+#endif
 constexpr size_t CTL_BYTES = 8 * sizeof(DRenderCtl);   // the control block and the debug records behind it
 // layout: control block | ox oy oz dx dy dz t (MAX_RAYS doubles each) | surface codes (MAX_RAYS u32)
 constexpr size_t OFF_F64 = (CTL_BYTES + 255) & ~(size_t)255;
@@ -46,7 +50,10 @@ int rtx::noalloc_setup_current_device() {
     std::lock_guard<std::mutex> lock(g_mutex);
     if (g_scratch[dev]) return RTX_OK;
     void* p = nullptr;
-    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    {
+        ColdTimer cold("hipGetSymbolAddress of the scratch array (loads the library's code object)");
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    }
     if (!p) return api_fail(RTX_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
     g_scratch[dev] = static_cast<unsigned char*>(p);
     return RTX_OK;
@@ -61,10 +68,24 @@ extern "C" int rtx_trace_closest_device(rtx_scene* sc, const double* d_org, cons
     if (counting(flags) || (flags & RTX_FLAG_TIME_KERNELS))
         return api_fail(RTX_ERR_BAD_ARG, "rtx_trace_closest_device: counting and timing flags need rtx_trace_closest (there is no stats output here)");
     if (n == 0) return RTX_OK;
-    HIP_TRY(hipSetDevice(sc->device));
+    // The caller's current device is left as it was: a capture or a serving loop on another device goes on undisturbed.
+    struct DeviceGuard {
+        int prior = -1;
+        ~DeviceGuard() { if (prior >= 0) (void)hipSetDevice(prior); }
+    } guard;
+    int current = 0;
+    HIP_TRY(hipGetDevice(&current));
+    if (current != sc->device) {
+        HIP_TRY(hipSetDevice(sc->device));
+        guard.prior = current;
+    }
     int rc = noalloc_setup_current_device();   // a lookup; the scene's creation has normally done it already
     if (rc != RTX_OK) return rc;
-    unsigned char* const base = g_scratch[sc->device];
+    unsigned char* base = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        base = g_scratch[sc->device];
+    }
     hipStream_t s = (hipStream_t)stream;
 
     DRenderCtl* ctl = reinterpret_cast<DRenderCtl*>(base);
@@ -76,10 +97,9 @@ extern "C" int rtx_trace_closest_device(rtx_scene* sc, const double* d_org, cons
     hits.t = f + 6 * n;
     hits.prim = reinterpret_cast<uint32_t*>(base + OFF_U32);
 
-    const uint32_t max_waves = sc->n_cus * env_u32("RTX_WAVES_PER_CU", 20);
     uint32_t n_sub;
     uint64_t sub_capacity;
-    pool_geometry(n, max_waves, &n_sub, &sub_capacity);
+    pool_geometry(n, sc->trace_max_waves, &n_sub, &sub_capacity);
     const DPool pool{nullptr, n_sub, (uint32_t)sub_capacity, (uint32_t)n};
 
     // The array keeps what the last call left: the control block starts at zero, the rest is overwritten before it is read.

@@ -646,6 +646,7 @@ struct RenderRunner {   // src/runner.rs:8-20
     uint64_t seed = 0;   // the reference seeds from the OS; a fixed seed makes a render repeatable
     bool build_on_device = false;   // BVH::from_slice_on_device instead of the host builder
     int n_gpus = 1;                 // > 1: samples per pixel split over that many GPUs of this node, one RCCL reduce (rtx_multi_*)
+    bool through_multi = false;     // take the rtx_multi_* path even with one GPU (a world of one: communicator, reduce and scaling still run)
 
     // src/runner.rs:23-41: build the BVH, render, write the P3 image to
     // `image_out` (the reference prints to stdout) and the three timers to
@@ -663,7 +664,7 @@ struct RenderRunner {   // src/runner.rs:8-20
         std::vector<char> text(image_out ? rtx_ppm_text_bound(cam.image_width, cam.image_height) : 0);   // src/camera.rs:129-131,155-161
         uint64_t text_len = 0;
         rtx_stats stats{};
-        if (n_gpus > 1) {
+        if (n_gpus > 1 || through_multi) {
             // the scene on every device and the communicator once, then one frame: one host thread per device, one reduce onto device 0
             rtx_multi* multi = nullptr;
             if (rtx_multi_create(&desc, n_gpus, &multi) != RTX_OK) throw RenderError(rtx_last_error());

@@ -159,7 +159,7 @@ int rth_example(const char* name, uint64_t scene_seed, rtx_surface* surfaces, ui
 }
 
 static int run_impl(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_t buckets, const rtx_camera_config* cfg,
-                    uint64_t seed, const char* ppm_path, double* out_rgb, bool build_on_device, int n_gpus = 1) {
+                    uint64_t seed, const char* ppm_path, double* out_rgb, bool build_on_device, int n_gpus = 1, bool through_multi = false) {
     if (!cfg || (n && !surfaces)) {
         g_err = "rth_run: null argument";
         return RTX_ERR_BAD_ARG;
@@ -172,6 +172,7 @@ static int run_impl(const rtx_surface* surfaces, uint32_t n, int strategy, uint3
         runner.seed = seed;
         runner.build_on_device = build_on_device;
         runner.n_gpus = n_gpus;
+        runner.through_multi = through_multi;
         if (ppm_path) {
             f = std::fopen(ppm_path, "wb");
             if (!f) throw RenderError(std::string("cannot open ") + ppm_path);
@@ -207,7 +208,7 @@ int rth_run_multi(const rtx_surface* surfaces, uint32_t n, int strategy, uint32_
         g_err = "rth_run_multi: n_gpus must be at least 1";
         return RTX_ERR_BAD_ARG;
     }
-    return run_impl(surfaces, n, strategy, buckets, cfg, seed, ppm_path, out_rgb, false, n_gpus);
+    return run_impl(surfaces, n, strategy, buckets, cfg, seed, ppm_path, out_rgb, false, n_gpus, true);   // also with one GPU: communicator, reduce, scaling
 }
 
 }  // extern "C"

@@ -69,3 +69,30 @@ def test_runner_on_several_gpus_writes_the_same_image(rt, oracle, tmp_path):
     want = f"P3\n{icam.image_width} {icam.image_height}\n255\n" + "".join(f"{r} {g} {b}\n" for r, g, b in q.tolist())
     assert path.read_bytes() == want.encode()
     assert rt._lib.rth_run_multi(surfaces.ctypes.data_as(C.c_void_p), len(surfaces), 3, 0, C.byref(cfg), 21, 0, None, ptr(multi)) == -1
+
+
+@pytest.mark.parametrize("how", ["--force-spawn", "--single-process"])
+def test_bench_launch_paths_with_a_world_of_one(how):
+    """bench.py's two N-GPU launch paths with N = 1 (all a one-GPU box can run): ranks started as child processes of
+    `python bench.py --gpus N` (watched, one per GPU, torch.distributed over RCCL), and the frame through rtx_multi_render
+    from one process.  The line must say that the collective saw every rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), how, "--gpus", "1", "--steps", "1", "--warmup", "0", "--spp", "8", "--width", "480",
+           "--no-cpu-baseline", "--no-pmc", "--no-cold-frame"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout          # stdout carries the JSON line and nothing else
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["ranks_in_collective"] == 1
+    assert d["value"] > 0 and d["config"]["paths_per_frame"] == 480 * 270 * 8
+    if how == "--single-process":
+        assert d["per_rank"]["spp_count"] == [8] and d["per_rank"]["ms_render"][0] > 0 and d["per_rank"]["ms_reduce"] >= 0
+    else:
+        assert d["image_check"]["rays_equal"] and d["image_check"]["max_rel_diff"] <= 1e-12
+        assert d["image_check"]["timed_form"] != d["image_check"]["other_form"]

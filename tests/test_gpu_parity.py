@@ -507,6 +507,37 @@ def test_headline_size_properties(rt, oracle):
     assert np.array_equal(img[0, 0], [0.7, 0.8, 1.0])
 
 
+def test_rows_without_survivors_and_without_radiance(rt, oracle, monkeypatch):
+    """The pooled kernel's one-block-per-CU form issues a row's atomics and stores by inline assembly with a fixed count per
+    row and waits by that count; lanes with nothing to add or store are masked out.  With a black sky and a depth limit of one
+    EVERY row has an empty mask in all sixteen operations (no path survives its first bounce, nothing is emitted, the sky adds
+    zero); with a limit of two the rows of the second bounce do.  Image and ray count are the oracle's and the round loop's,
+    whose shade kernel is plain C++."""
+    import torch
+
+    surfaces, cam = S.cover_spheres()
+    cam = dict(cam, image_width=256, background=(0.0, 0.0, 0.0))
+    stream = torch.cuda.current_stream().cuda_stream
+    for max_depth in (1, 2):
+        c = dict(cam, max_depth=max_depth)
+        icam = rt.camera_initialize(c)
+        want, ctr = oracle.Scene(surfaces).render(oracle.camera_initialize(c), 6, 2, 3, iterative=True)
+        for env in ({"RTX_RESIDENT": "0"}, {"RTX_PERSISTENT": "0"}):
+            for k in ("RTX_RESIDENT", "RTX_PERSISTENT"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            dev = rt.Scene(rt.HostBVH(surfaces))
+            acc = torch.zeros(icam.image_height, icam.image_width, 3, dtype=torch.float64, device="cuda")
+            st = dev.render_accumulate(icam, 6, 2, 3, acc.data_ptr(), stream)
+            assert st.kernel_form == (rt.FORM_POOLED if "RTX_RESIDENT" in env else rt.FORM_ROUND_LOOP)
+            assert st.rays == ctr.rays and st.paths == ctr.paths
+            got = acc.cpu().numpy()
+            assert np.allclose(got, want, rtol=1e-13, atol=0)
+            if max_depth == 1:
+                assert st.rays == st.paths and not got.any()
+
+
 def test_headline_frame_in_both_forms_of_the_kernel(rt, oracle, monkeypatch):
     """cover_spheres at the benchmark's 1920x1080 in the form the benchmark times (paths resident in registers) and in the
     pooled form: the same rays, paths and image (up to the order of the f64 sums) at 9 samples per pixel -- 1.9e7 paths, so

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(rt):
 def test_struct_layouts_match_headers(rt, oracle):
     assert ctypes.sizeof(rt.Camera) == 16 + 8 + 24 + 8 + 6 * 24
     assert ctypes.sizeof(rt.CameraConfig) == ctypes.sizeof(oracle.CameraConfig) == 8 + 16 + 8 + 72 + 16 + 24
-    assert ctypes.sizeof(rt.Stats) == 7 * 8 + 4 * 8
+    assert ctypes.sizeof(rt.Stats) == 7 * 8 + 4 * 8 + 2 * 4
     assert ctypes.sizeof(rt.SceneDesc) == 16 + 17 * 8
     assert ctypes.sizeof(rt.MultiStats) == 16 + 8 + 16 + rt.MULTI_MAX_GPUS * (4 + 4 + 8 + 8)
     assert rt.SURFACE_DTYPE.itemsize == 120

@@ -112,3 +112,25 @@ def test_reduce_rejects_non_f64():
 
     with pytest.raises(TypeError):
         reduce_accum(torch.zeros(4, dtype=torch.float32), 1)
+
+
+def test_bench_launcher_ends_all_ranks_when_one_dies():
+    """`python bench.py --gpus 3` on a machine that has fewer GPUs (none here): every rank fails when it asks for its device.
+    The launcher must notice, end the others instead of leaving them in a rendezvous, say which rank died with its last lines,
+    and exit non-zero within seconds."""
+    import subprocess
+    import sys
+    import time
+
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 3:
+        pytest.skip("this machine has the GPUs the test counts on not having")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0", "--spp", "2", "--no-cpu-baseline",
+                        "--no-pmc"], capture_output=True, text=True, timeout=280)
+    assert r.returncode != 0
+    assert time.time() - t0 < 120
+    assert "rank" in r.stderr and "exited with status" in r.stderr
+    assert r.stdout.strip() == ""

@@ -121,3 +121,39 @@ def test_no_alloc_entry_leaves_device_memory_as_it_is(rt):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (16 << 20), (free0, free1)
+
+
+def test_no_alloc_entry_under_graph_capture(rt):
+    """What the entry point is for: two calls captured into a HIP graph (no allocation, no wait, no change of the current
+    device may happen under capture), replayed on new inputs, against rtx_trace_closest."""
+    import torch
+
+    surfaces, cam = S.cover_spheres()
+    dev = rt.Scene(rt.HostBVH(surfaces))
+    icam = rt.camera_initialize(dict(cam, image_width=320))
+    org, d = rt.primary_rays(icam, 4, 1)
+    n, k = len(org), 5003
+    rng = np.random.default_rng(8)
+    d_org, d_dir = torch.zeros(n, 3, dtype=torch.float64, device="cuda"), torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    id_a, id_b = torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(k, dtype=torch.int32, device="cuda")
+    t_a, t_b = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros(k, dtype=torch.float64, device="cuda")
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        s = torch.cuda.current_stream().cuda_stream
+        dev.trace_closest_device(d_org.data_ptr(), d_dir.data_ptr(), n, id_a.data_ptr(), t_a.data_ptr(), stream=s)
+        # the second call reads the first k rays again, through the exact box test: ordered behind the first on the same stream
+        dev.trace_closest_device(d_org.data_ptr(), d_dir.data_ptr(), k, id_b.data_ptr(), t_b.data_ptr(), flags=rt.FLAG_EXACT_DIVIDE, stream=s)
+    for rays in ((org, d), (org + d * 0.3, rng.normal(size=d.shape))):
+        d_org.copy_(torch.from_numpy(np.ascontiguousarray(rays[0])))
+        d_dir.copy_(torch.from_numpy(np.ascontiguousarray(rays[1])))
+        id_a.fill_(0x5A5A5A5A)
+        t_b.fill_(-1.0)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        want_id, want_t, _ = dev.trace_closest(rays[0], rays[1])
+        assert np.array_equal(id_a.cpu().numpy().view(np.uint32), want_id) and np.array_equal(bits(t_a.cpu().numpy()), bits(want_t))
+        assert np.array_equal(id_b.cpu().numpy().view(np.uint32), want_id[:k]) and np.array_equal(bits(t_b.cpu().numpy()), bits(want_t[:k]))
+        assert (want_id != NONE).any() and (want_id == NONE).any()
