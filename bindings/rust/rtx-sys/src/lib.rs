@@ -5,7 +5,7 @@
 use std::os::raw::{c_char, c_int, c_void};
 
 pub const RTX_NONE: u32 = 0xFFFF_FFFF;
-pub const RTX_TRACE_DEVICE_MAX_RAYS: u64 = 1 << 20;
+pub const RTX_TRACE_DEVICE_MAX_RAYS: u64 = 1 << 18;
 
 // enum rtx_status
 pub const RTX_OK: c_int = 0;

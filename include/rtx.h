@@ -195,7 +195,8 @@ int rtx_trace_closest(rtx_scene* scene, const double* org, const double* dir, ui
  *     [n][3], [n], [n]);
  *   - the per-component ray arrays, hit records and control block the kernels
  *     work on live in a fixed scratch array inside the library's code object
- *     (about 60 MiB per GPU, held until the process ends) instead of buffers
+ *     (15 MiB per GPU, held until the process ends; loading it costs a
+ *     process about 5 ms once, 4x that for a 2^20-ray array, which is why it is not larger) instead of buffers
  *     allocated on demand, so n is limited to RTX_TRACE_DEVICE_MAX_RAYS (larger
  *     batches are rejected with RTX_ERR_BAD_ARG: split them);
  *   - the work is enqueued on `stream` (a hipStream_t, NULL = default stream)
@@ -206,7 +207,7 @@ int rtx_trace_closest(rtx_scene* scene, const double* org, const double* dir, ui
  * The call makes no hipMalloc/hipFree.  Every call on a GPU uses that GPU's one
  * scratch array: calls that overlap on one GPU (two streams, two threads, two
  * scenes) race; order them. */
-#define RTX_TRACE_DEVICE_MAX_RAYS (1u << 20)
+#define RTX_TRACE_DEVICE_MAX_RAYS (1u << 18)
 int rtx_trace_closest_device(rtx_scene* scene, const double* d_org, const double* d_dir, uint64_t n,
                              double tmin, double tmax, uint32_t flags,
                              uint32_t* d_out_id, double* d_out_t, void* stream);

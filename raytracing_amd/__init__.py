@@ -36,7 +36,7 @@ FLAG_NO_WAIT = 32
 FLAG_COUNT_ACTUAL = 64
 FORM_NONE, FORM_ROUND_LOOP, FORM_POOLED, FORM_RESIDENT = 0, 1, 2, 3
 FORM_KERNEL = {FORM_ROUND_LOOP: "k_generate + k_traverse_f32 + k_shade", FORM_POOLED: "k_render_persistent", FORM_RESIDENT: "k_render_resident"}
-TRACE_DEVICE_MAX_RAYS = 1 << 20
+TRACE_DEVICE_MAX_RAYS = 1 << 18
 
 BISECT, MIDPOINT, SAH_EQUAL_SIZE, SAH_PER_SURFACE = 0, 1, 2, 3
 

@@ -533,17 +533,18 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     sc->d.n_nodes = n;
     sc->d.filter_ok = filter_ok ? 1u : 0u;
     sc->d.batch_undecided = batch_undecided;
-    // Waiting for more lanes before the surface tests run pays where those tests are the larger part of the walk:
-    // scenes of quads and triangles (57 flop a test, and their tripled boxes are hit often); most where the whole scene sits in LDS
-    // (32 lanes; 40 was 1.8 % better on the Cornell box while undecided box tests still counted as waiting lanes, and is 4 % worse
-    // since flagged nodes no longer wait: 9633 against 10035 Mrays/s; a 10^6-triangle tree in global memory loses 4.5 % with 40).
+    // Waiting for more lanes before the surface tests run pays where those tests are a large part of the walk: scenes of quads
+    // and triangles (57 flop a test).  With the reference's tripled boxes such scenes made 4 to 55 surface tests per ray and 32
+    // waiting lanes were best; culled with the smaller boxes above they make 1.6 to 7, and 24 are: Cornell box 273.6 against
+    // 277.8 ms per 2000 spp, 10^6 triangles 804 against 851 ms per 20 spp (16: 808, 8: 842).
     const size_t scene_bytes = (size_t)n * sizeof(DNode32) + spheres.size() * sizeof(DSphere) + planars.size() * sizeof(DPlanar);
     const bool planar_scene = planars.size() > spheres.size(), small_scene = scene_bytes <= 32u * 1024u;
-    sc->d.pend_at = env_u32("RTX_PEND_AT", planar_scene ? 32u : 16u);
+    sc->d.pend_at = env_u32("RTX_PEND_AT", planar_scene ? 24u : 16u);
     if (sc->d.pend_at > 64u) sc->d.pend_at = 64u;
-    // Idle lanes take their next rays once 32 lanes are idle; once 16 are where the whole scene sits in LDS and the surface tests
-    // dominate (Cornell box +8 %, quads +4 %; the headline scene loses 2 % with 16, a 10^6-triangle tree in global memory 5 %).
-    sc->d.refill_at = env_u32("RTX_REFILL_AT", planar_scene && small_scene ? 16u : 32u);
+    // Idle lanes take their next rays once 32 lanes are idle; once 24 are where the whole scene sits in LDS and is made of quads
+    // and triangles (Cornell box: 16 / 24 idle lanes 275.8 / 273.6 ms per 2000 spp; the headline scene loses 2 % with 16, a
+    // 10^6-triangle tree in global memory loses 0.8 % with 16 and 19 % with 48).
+    sc->d.refill_at = env_u32("RTX_REFILL_AT", planar_scene && small_scene ? 24u : 32u);
     if (sc->d.refill_at > 64u) sc->d.refill_at = 64u;
     // The kernel that keeps the paths in registers runs a bounce (some 1500 instructions whatever the number of lanes in it) once this
     // many lanes are due: 16 / 24 / 32 / 40 / 48 / 56 / 64 give 51.8 / 45.2 / 42.5 / 40.7 / 40.3 / 40.4 / 44.9 ms per 100 spp of the headline frame
