@@ -255,6 +255,7 @@ extern "C" {
     ) -> c_int;
     pub fn rtx_selftest_math(op: c_int, a: *const f64, b: *const f64, n: u64, out: *mut f64) -> c_int;
     pub fn rtx_selftest_rng(seed: u64, pixel: u32, sample: u32, n: u32, out: *mut f64) -> c_int;
+    pub fn rtx_selftest_cull_boxes(desc: *const rtx_scene_desc, shrink: c_int, out_bmin: *mut f64, out_bmax: *mut f64, out_differ: *mut u32) -> c_int;
 }
 
 #[cfg(test)]

@@ -316,6 +316,12 @@ int rtx_render_multi(const rtx_scene_desc* desc, const rtx_camera* cam, uint64_t
  * op 3: out[i] = (float)a[i] / (float)b[i] in single precision. */
 int rtx_selftest_math(int op, const double* a, const double* b, uint64_t n, double* out);
 
+/* The boxes the closest-hit walk tests first (host arithmetic only, no device needed): for every node of `desc` the
+ * reference's box, or -- shrink != 0, as rtx_scene_create does unless RTX_TIGHT_BOXES=0 -- a smaller box for nodes above
+ * quads and triangles, chosen so that no hit can change (the reference pads such boxes to three times the surface's extent,
+ * src/aabb.rs:78-87).  out_bmin / out_bmax: host, [3][n_nodes]; *out_differ = nodes whose box is smaller than the reference's. */
+int rtx_selftest_cull_boxes(const rtx_scene_desc* desc, int shrink, double* out_bmin, double* out_bmax, uint32_t* out_differ);
+
 /* Philox4x32-7 uniform doubles of stream (seed, pixel, sample) computed on the device. */
 int rtx_selftest_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, double* out);
 

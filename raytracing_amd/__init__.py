@@ -123,7 +123,7 @@ class BuildStats(C.Structure):  # rtx_build_stats
 ABI_SYMBOLS = [
     "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy", "rtx_trace_closest", "rtx_trace_closest_device",
     "rtx_primary_rays", "rtx_render_accumulate", "rtx_scale", "rtx_quantize", "rtx_render", "rtx_selftest_math",
-    "rtx_selftest_rng", "rtx_bvh_build", "rtx_multi_create", "rtx_multi_destroy", "rtx_multi_render", "rtx_multi_image", "rtx_render_multi", "rtx_ppm_text_bound", "rtx_ppm_text", "rtx_render_ppm",
+    "rtx_selftest_rng", "rtx_selftest_cull_boxes", "rtx_bvh_build", "rtx_multi_create", "rtx_multi_destroy", "rtx_multi_render", "rtx_multi_image", "rtx_render_multi", "rtx_ppm_text_bound", "rtx_ppm_text", "rtx_render_ppm",
     "rth_last_error", "rth_bvh_build", "rth_bvh_build_device", "rth_run_device_build", "rth_example", "rth_bvh_desc", "rth_bvh_destroy", "rth_camera_initialize", "rth_run", "rth_run_multi",
 ]
 
@@ -149,6 +149,7 @@ _lib.rtx_multi_image.restype = C.c_void_p
 _lib.rtx_render_multi.argtypes = [_p(SceneDesc), _p(Camera), C.c_uint64, C.c_int, C.c_uint32, _dp, _p(MultiStats)]
 _lib.rtx_selftest_math.argtypes = [C.c_int, _dp, _dp, C.c_uint64, _dp]
 _lib.rtx_selftest_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _dp]
+_lib.rtx_selftest_cull_boxes.argtypes = [_p(SceneDesc), C.c_int, _dp, _dp, _u32p]
 _lib.rth_bvh_build.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, _p(C.c_void_p)]
 _lib.rth_bvh_build_device.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, _p(C.c_void_p), _p(BuildStats)]
 _lib.rtx_bvh_build.argtypes = [_dp, C.c_uint32, C.c_int, C.c_uint32, _u32p, _dp, _dp, _u32p, _u32p, _p(BuildStats)]
@@ -396,6 +397,16 @@ def selftest_math(op, a, b):
     out = np.empty_like(a)
     _check(_lib.rtx_selftest_math(op, _ptr(a, _dp), _ptr(b, _dp), a.size, _ptr(out, _dp)))
     return out
+
+
+def cull_boxes(bvh, shrink=True):
+    """``rtx_selftest_cull_boxes``: (bmin[3, n], bmax[3, n], nodes whose box is smaller than the reference's) of a HostBVH."""
+    desc = bvh.desc if isinstance(bvh, HostBVH) else bvh
+    n = int(desc.n_nodes)
+    bmin, bmax = np.zeros((3, n)), np.zeros((3, n))
+    differ = C.c_uint32(0)
+    _check(_lib.rtx_selftest_cull_boxes(C.byref(desc), 1 if shrink else 0, _ptr(bmin, _dp), _ptr(bmax, _dp), C.byref(differ)))
+    return bmin, bmax, int(differ.value)
 
 
 def selftest_rng(seed, pixel, sample, n):

@@ -165,6 +165,58 @@ void rtx::run_traverse(const rtx_scene* sc, const DState& rays, const DHits& hit
     }
 }
 
+// The cull boxes of a validated scene description (see the comment where rtx_scene_create calls this): cull[i] is the box the
+// walk's first tier tests at node i.  Children follow their parents in pre-order, so one backward pass sees every child before
+// its parent.  Returns the number of nodes whose cull box differs from the reference's.  Host arithmetic only.
+uint32_t rtx::compute_cull_boxes(const rtx_scene_desc& desc, bool shrink, std::vector<DBox64>& cull) {
+    const uint32_t n = desc.n_nodes, m = desc.n_prims;
+    cull.assign(n, DBox64{});
+    uint32_t n_cull = 0;
+    for (uint32_t i = n; i-- > 0u;) {
+        DBox64& c = cull[i];
+        double rmin[3], rmax[3];   // the reference's box
+        for (int a = 0; a < 3; ++a) {
+            c.bmin[a] = rmin[a] = desc.node_bmin[(size_t)a * n + i];
+            c.bmax[a] = rmax[a] = desc.node_bmax[(size_t)a * n + i];
+        }
+        if (!shrink) continue;
+        const uint32_t prim = desc.node_prim[i];
+        double lo[3], hi[3];
+        bool ok = true;
+        if (prim != RTX_NONE) {
+            if (desc.prim_kind[prim] == RTX_SPHERE) continue;
+            const bool quad = desc.prim_kind[prim] == RTX_QUAD;
+            for (int a = 0; a < 3 && ok; ++a) {
+                const double q = desc.prim_q[(size_t)a * m + prim], u = desc.prim_u[(size_t)a * m + prim], v = desc.prim_v[(size_t)a * m + prim];
+                const double p0 = q, p1 = q + u, p2 = q + v, p3 = quad ? q + u + v : p0;
+                const double tlo = std::fmin(std::fmin(p0, p1), std::fmin(p2, p3)), thi = std::fmax(std::fmax(p0, p1), std::fmax(p2, p3));
+                const double big = std::fmax(std::fabs(rmin[a]), std::fabs(rmax[a]));
+                const double need = std::fmax(1e-9 * big, 1e-6 * (std::fabs(u) + std::fabs(v))) + 1e-300;
+                const double grow = std::fmax(need, 0x1.0p-13 * big);
+                lo[a] = std::fmax(tlo - grow, rmin[a]);
+                hi[a] = std::fmin(thi + grow, rmax[a]);
+                ok = tlo - lo[a] >= need && hi[a] - thi >= need;   // (false for a NaN anywhere)
+            }
+        } else {
+            const DBox64 &l = cull[i + 1], &r = cull[desc.node_right[i]];
+            for (int a = 0; a < 3 && ok; ++a) {
+                lo[a] = std::fmin(l.bmin[a], r.bmin[a]);
+                hi[a] = std::fmax(l.bmax[a], r.bmax[a]);
+                ok = lo[a] >= rmin[a] && hi[a] <= rmax[a];
+            }
+        }
+        if (!ok) continue;
+        bool differs = false;
+        for (int a = 0; a < 3; ++a) {
+            differs = differs || lo[a] != rmin[a] || hi[a] != rmax[a];
+            c.bmin[a] = lo[a];
+            c.bmax[a] = hi[a];
+        }
+        if (differs) ++n_cull;
+    }
+    return n_cull;
+}
+
 extern "C" {
 
 const char* rtx_last_error(void) { return g_err.c_str(); }
@@ -335,51 +387,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     // Visits the first tier cannot decide go to the f64 tiers with the reference's own box, as before.  Only the numbers of
     // box and surface tests change, so calls that count the reference's work (RTX_FLAG_COUNT_WORK) walk tables made from R.
     // C is kept thick enough for single precision to resolve (2^-13 of the largest coordinate per side, R permitting).
-    const bool want_cull = env_u32("RTX_TIGHT_BOXES", 1, true) != 0u;
-    std::vector<DBox64> cull(n);
-    uint32_t n_cull = 0;   // nodes whose cull box differs from the reference's
-    for (uint32_t i = n; i-- > 0u;) {
-        DBox64& c = cull[i];
-        const DNode& nd = nodes[i];
-        for (int a = 0; a < 3; ++a) {
-            c.bmin[a] = nd.bmin[a];
-            c.bmax[a] = nd.bmax[a];
-        }
-        if (!want_cull) continue;
-        const uint32_t prim = desc->node_prim[i];
-        double lo[3], hi[3];
-        bool ok = true;
-        if (prim != RTX_NONE) {
-            if (prims[prim].kind == RTX_SPHERE) continue;
-            const DPlanar& g = planars[prims[prim].slot];
-            const bool quad = prims[prim].kind == RTX_QUAD;
-            for (int a = 0; a < 3 && ok; ++a) {
-                const double p0 = g.q[a], p1 = g.q[a] + g.u[a], p2 = g.q[a] + g.v[a], p3 = quad ? g.q[a] + g.u[a] + g.v[a] : p0;
-                const double tlo = std::fmin(std::fmin(p0, p1), std::fmin(p2, p3)), thi = std::fmax(std::fmax(p0, p1), std::fmax(p2, p3));
-                const double big = std::fmax(std::fabs(nd.bmin[a]), std::fabs(nd.bmax[a]));
-                const double need = std::fmax(1e-9 * big, 1e-6 * (std::fabs(g.u[a]) + std::fabs(g.v[a]))) + 1e-300;
-                const double grow = std::fmax(need, 0x1.0p-13 * big);
-                lo[a] = std::fmax(tlo - grow, nd.bmin[a]);
-                hi[a] = std::fmin(thi + grow, nd.bmax[a]);
-                ok = tlo - lo[a] >= need && hi[a] - thi >= need;   // (false for a NaN anywhere)
-            }
-        } else {
-            const DBox64 &l = cull[i + 1], &r = cull[desc->node_right[i]];
-            for (int a = 0; a < 3 && ok; ++a) {
-                lo[a] = std::fmin(l.bmin[a], r.bmin[a]);
-                hi[a] = std::fmax(l.bmax[a], r.bmax[a]);
-                ok = lo[a] >= nd.bmin[a] && hi[a] <= nd.bmax[a];
-            }
-        }
-        if (!ok) continue;
-        bool differs = false;
-        for (int a = 0; a < 3; ++a) {
-            differs = differs || lo[a] != nd.bmin[a] || hi[a] != nd.bmax[a];
-            c.bmin[a] = lo[a];
-            c.bmax[a] = hi[a];
-        }
-        if (differs) ++n_cull;
-    }
+    std::vector<DBox64> cull;
+    const uint32_t n_cull = compute_cull_boxes(*desc, env_u32("RTX_TIGHT_BOXES", 1, true) != 0u, cull);   // nodes whose cull box differs from the reference's
     // f32 records of the cull boxes; `nodes32` keeps the reference's planes for the calls that count its work
     std::vector<DNode32> nodes32_cull;
     if (n_cull) {
@@ -1136,6 +1145,32 @@ int rtx_render_ppm(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, uint32_t
 int rtx_render(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, uint32_t flags, double* out_rgb, rtx_stats* stats) {
     if (!out_rgb) return fail(RTX_ERR_BAD_ARG, "rtx_render: null argument");
     return rtx_render_ppm(sc, cam, seed, flags, out_rgb, nullptr, 0, nullptr, stats);
+}
+
+int rtx_selftest_cull_boxes(const rtx_scene_desc* desc, int shrink, double* out_bmin, double* out_bmax, uint32_t* out_differ) {
+    if (!desc || !out_bmin || !out_bmax) return fail(RTX_ERR_BAD_ARG, "rtx_selftest_cull_boxes: null argument");
+    const uint32_t n = desc->n_nodes, m = desc->n_prims;
+    if (n && (!desc->node_bmin || !desc->node_bmax || !desc->node_right || !desc->node_prim))
+        return fail(RTX_ERR_BAD_ARG, "rtx_selftest_cull_boxes: null node table");
+    for (uint32_t i = 0; i < n; ++i) {   // what compute_cull_boxes relies on (rtx_scene_create checks more)
+        const uint32_t prim = desc->node_prim[i], right = desc->node_right[i];
+        if (prim != RTX_NONE) {
+            if (prim >= m || !desc->prim_kind || !desc->prim_q || desc->prim_kind[prim] > RTX_TRIANGLE)
+                return fail(RTX_ERR_BAD_ARG, "rtx_selftest_cull_boxes: bad leaf");
+            if (desc->prim_kind[prim] != RTX_SPHERE && (!desc->prim_u || !desc->prim_v)) return fail(RTX_ERR_BAD_ARG, "rtx_selftest_cull_boxes: null planar table");
+        } else if (right == RTX_NONE || right <= i + 1 || right >= n) {
+            return fail(RTX_ERR_BAD_ARG, "rtx_selftest_cull_boxes: malformed tree");
+        }
+    }
+    std::vector<DBox64> cull;
+    const uint32_t differ = compute_cull_boxes(*desc, shrink != 0, cull);
+    for (uint32_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            out_bmin[(size_t)a * n + i] = cull[i].bmin[a];
+            out_bmax[(size_t)a * n + i] = cull[i].bmax[a];
+        }
+    if (out_differ) *out_differ = differ;
+    return RTX_OK;
 }
 
 int rtx_selftest_math(int op, const double* a, const double* b, uint64_t n, double* out) {

@@ -168,6 +168,9 @@ inline DScene scene_tables(const rtx_scene* sc, uint32_t flags) {
     return d;
 }
 
+// The boxes the walk's first tier tests (rtx_api.cpp), from a validated scene description; returns how many differ from the reference's.
+uint32_t compute_cull_boxes(const rtx_scene_desc& desc, bool shrink, std::vector<DBox64>& cull);
+
 // Closest hit of the rays in `rays` (per-component arrays) cut into `pool`'s sub-pools, with the box-test tier
 // `flags` asks for; hit records go to `hits`.  `ctl` receives the work counters of RTX_FLAG_COUNT_WORK.
 void run_traverse(const rtx_scene* sc, const DState& rays, const DHits& hits, const DPool& pool, double tmin, double tmax,
