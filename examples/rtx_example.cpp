@@ -69,6 +69,7 @@ int main(int argc, char** argv) {
         if (spp > 0) e.camera.samples_per_pixel = (uint32_t)spp;
         if (depth > 0) e.camera.max_depth = (uint32_t)depth;
         runner.camera = e.camera;
+        runner.keep_image = false;   // only the P3 text is wanted, as in the reference
         if (out_path && !(image_out = std::fopen(out_path, "wb"))) {
             std::fprintf(stderr, "rtx_example: cannot open %s\n", out_path);
             return 1;

@@ -1135,10 +1135,14 @@ int rtx_render_ppm(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, uint32_t
     rc = rtx_scale(acc.p, nval, cam->pixel_samples_scale, acc.p, nullptr);
     if (rc != RTX_OK) return rc;
     if (out_text) {
+        ColdTimer cold("P3 text on the device and its copy to the host");
         rc = rtx_ppm_text(acc.p, cam->image_width, cam->image_height, out_text, capacity, out_len, nullptr);
         if (rc != RTX_OK) return rc;
     }
-    if (out_rgb) HIP_TRY(hipMemcpy(out_rgb, acc.p, nval * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_rgb) {
+        ColdTimer cold("copy of the linear image to the host");
+        HIP_TRY(hipMemcpy(out_rgb, acc.p, nval * sizeof(double), hipMemcpyDeviceToHost));
+    }
     return RTX_OK;
 }
 

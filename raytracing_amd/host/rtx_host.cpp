@@ -173,6 +173,7 @@ static int run_impl(const rtx_surface* surfaces, uint32_t n, int strategy, uint3
         runner.build_on_device = build_on_device;
         runner.n_gpus = n_gpus;
         runner.through_multi = through_multi;
+        runner.keep_image = out_rgb != nullptr || ppm_path == nullptr;
         if (ppm_path) {
             f = std::fopen(ppm_path, "wb");
             if (!f) throw RenderError(std::string("cannot open ") + ppm_path);

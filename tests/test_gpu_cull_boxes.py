@@ -148,3 +148,67 @@ def test_cull_boxes_and_degenerate_rays(rt, oracle):
         ids, t, _ = dev.trace_closest(org, d, flags=flags)
         assert np.array_equal(ids, wid) and np.array_equal(bits(t), bits(np.where(wid == NONE, np.inf, wt)))
     assert (wid != NONE).sum() > 1000
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_far_from_the_origin_flat_and_tiny(rt, oracle, seed, monkeypatch):
+    """Scenes drawn at random: 1 to 300 surfaces of every kind, sizes from 1e-3 to 30, the whole scene shifted up to 1e6 away
+    from the origin (where the room a box must leave around a surface is set by the coordinates, not by the surface), a share
+    of surfaces flat on an axis or degenerate (u parallel to v), every partition strategy.  Rays from inside and outside the
+    scene at three scales of direction length, traced by the product's walk with the tree in LDS, in global memory as f32
+    records and as quantised records: ids and distances are the oracle's bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 3, 7, 30, 120, 300]))
+    size = float(rng.choice([1e-3, 0.1, 1.0, 30.0]))
+    shift = rng.choice([0.0, 10.0, 1e3, 1e6]) * rng.normal(size=3)
+    extent = size * max(2.0, n ** (1 / 3)) * 2.0
+    out = []
+    mat = S.lambertian((0.5, 0.5, 0.5))
+    for i in range(n):
+        q = shift + rng.uniform(-extent, extent, 3)
+        k = rng.integers(0, 6)
+        if k == 0:
+            out.append(S.sphere(q, size * rng.uniform(0.2, 1.5), mat))
+        elif k == 1:
+            out.append(S.triangle(q, size * rng.uniform(-2, 2, 3), size * rng.uniform(-2, 2, 3), mat))
+        elif k == 2:
+            out.append(S.quad(q, size * rng.uniform(-2, 2, 3), size * rng.uniform(-2, 2, 3), mat))
+        elif k == 3:                       # flat on an axis
+            a = rng.integers(0, 3)
+            u, v = np.zeros(3), np.zeros(3)
+            u[(a + 1) % 3] = size * rng.uniform(0.5, 3.0)
+            v[(a + 2) % 3] = size * rng.uniform(0.5, 3.0)
+            out.append((S.quad if rng.random() < 0.5 else S.triangle)(q, u, v, mat))
+        elif k == 4:                       # sticks out of the reference's two-corner box
+            s = size * rng.uniform(0.5, 3.0)
+            out.append(S.quad(q, (s, 0.0, s), (-s, 0.0, s), mat))
+        else:                              # degenerate: no area, never hit; its box still takes part in the tree
+            u = size * rng.uniform(-2, 2, 3)
+            out.append(S.triangle(q, u, 2.0 * u, mat))
+    surfaces = S.pack(out)
+    orc = bvh = None
+    for k in range(3):   # the strategy of the seed, or the next one the reference's builder accepts for this scene
+        j = (seed + k) % 3
+        try:
+            orc = oracle.Scene(surfaces, [oracle.SAH_PER_SURFACE, oracle.BISECT, oracle.MIDPOINT][j])
+            bvh = rt.HostBVH(surfaces, [rt.SAH_PER_SURFACE, rt.BISECT, rt.MIDPOINT][j])
+            break
+        except (oracle.OracleError, rt.RtxError):   # no valid splitting plane, or a partition with an empty side
+            orc = bvh = None
+    if bvh is None:
+        pytest.skip("the reference's builders all reject this scene")
+    dev = rt.Scene(bvh)
+    monkeypatch.setenv("RTX_NODE16", "1")
+    dev16 = rt.Scene(bvh)
+    m = 20000
+    targets = surfaces["q"][rng.integers(0, n, m)] + size * rng.normal(size=(m, 3))
+    org = np.where(rng.random((m, 1)) < 0.5, shift + rng.uniform(-3 * extent, 3 * extent, (m, 3)), targets + extent * rng.normal(size=(m, 3)))
+    d = (targets - org) * rng.choice([1e-3, 1.0, 1e3], size=(m, 1))
+    d[rng.random((m, 3)) < 0.02] = 0.0
+    wid, wt, _ = orc.trace_closest(org, d)
+    want_t = bits(np.where(wid == NONE, np.inf, wt))
+    for scene, flags in ((dev, 0), (dev, rt.FLAG_NO_LDS), (dev16, rt.FLAG_NO_LDS)):
+        ids, t, _ = scene.trace_closest(org, d, flags=flags)
+        assert np.array_equal(ids, wid) and np.array_equal(bits(t), want_t), (seed, flags, int(np.count_nonzero(ids != wid)))
+    if n > 1:
+        assert (wid != NONE).any()
