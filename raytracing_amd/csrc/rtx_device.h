@@ -188,6 +188,7 @@ struct DRenderCtl {
     unsigned long long box_fallbacks;  // box tests the f32 tier left undecided
     uint32_t live_total;               // rays of the current round over all sub-pools (the host polls this)
     uint32_t rounds_max;               // single-launch render: most rounds any wave went through
+    unsigned long long band_next[8];   // single-launch render with the image cut into bands (one per XCD): next unstarted path of each band
 };
 
 // Everything the single-launch render kernel needs, in device memory: the
@@ -207,6 +208,7 @@ struct DRenderParams {
     uint32_t tile_order;    // path indices name pixels block by block (tiled_pixel) instead of row by row
     uint32_t tail_in_registers;   // the last row of rays of a wave finishes in registers (phase_tail)
     uint32_t resident_batch;      // resident form: primary rays a wave makes and stages at a time (64, or fewer where LDS is short)
+    uint32_t xcd_bands;           // pooled form: the image in this many bands with a path counter each (0 or 1: one counter for the whole image)
 };
 
 // ---------------------------------------------------------------- Vector3 (src/vector.rs)

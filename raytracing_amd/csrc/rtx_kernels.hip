@@ -299,15 +299,18 @@ __device__ __forceinline__ uint32_t tiled_pixel(uint32_t pos, uint32_t width) {
 }
 
 // The wave starts paths first .. first + n_new - 1 in slots slot0 .. of `st`.
+// region_base / region_npix: path indices count through the positions [region_base, region_base + region_npix) of the pixel
+// order only (region_npix = 0: through all of them).
 template <bool SCRAMBLE>
 __device__ __forceinline__ void generate_wave(const DCamera& cam, const DState& st, uint32_t slot0, unsigned long long first, uint32_t n_new,
-                                              uint64_t seed, uint32_t spp_begin, uint32_t tiled = 0u) {
-    const unsigned long long npix = (unsigned long long)cam.image_width * cam.image_height;
+                                              uint64_t seed, uint32_t spp_begin, uint32_t tiled = 0u, uint32_t region_base = 0u, uint32_t region_npix = 0u) {
+    const unsigned long long npix = region_npix ? (unsigned long long)region_npix : (unsigned long long)cam.image_width * cam.image_height;
     for (uint32_t i0 = 0; i0 < n_new; i0 += 64u) {   // whole rows: the lanes past the end help the others
         const uint32_t i = i0 + lane_id();
         const bool valid = i < n_new;
         uint32_t pixel, sample_off;
         split_path_index<SCRAMBLE>(first + (valid ? i : 0u), npix, pixel, sample_off);
+        if (!SCRAMBLE) pixel += region_base;
         if (!SCRAMBLE && tiled) pixel = tiled_pixel(pixel, cam.image_width);   // wave-uniform choice
         const uint32_t sample = spp_begin + sample_off;
         V3 o, d;
@@ -1470,13 +1473,15 @@ __device__ __forceinline__ DScene uniform_scene(const DScene& s) {
     u.n_spheres = uniform32(s.n_spheres); u.n_planars = uniform32(s.n_planars); u.assume_in_count = uniform32(s.assume_in_count);
     return u;
 }
-__device__ RTX_PHASE_INLINE void phase_generate(const DRenderParams* pp, uint32_t parity, uint32_t slot0, unsigned long long first, uint32_t got) {
+__device__ RTX_PHASE_INLINE void phase_generate(const DRenderParams* pp, uint32_t parity, uint32_t slot0, unsigned long long first, uint32_t got,
+                                                uint32_t region_base, uint32_t region_npix) {
     const DRenderParams* P = uniform_ptr(pp);
     parity = uniform32(parity);
     slot0 = uniform32(slot0);
     got = uniform32(got);
     first = uniform64(first);
-    generate_wave<false>(P->cam, uniform_state(P->st[parity]), slot0, first, got, uniform64(P->seed), uniform32(P->spp_begin), uniform32(P->tile_order));
+    generate_wave<false>(P->cam, uniform_state(P->st[parity]), slot0, first, got, uniform64(P->seed), uniform32(P->spp_begin), uniform32(P->tile_order),
+                         uniform32(region_base), uniform32(region_npix));
 }
 template <bool COUNT, bool LDS_NODES, bool BATCH, bool REC16>
 __device__ RTX_PHASE_INLINE void phase_traverse(const DRenderParams* pp, uint32_t parity, uint32_t base, uint32_t count, WorkCounters* wc) {
@@ -1623,6 +1628,11 @@ __device__ __forceinline__ void stage_scene_in_lds(const DRenderParams* P) {
 // The fifth wave is given up for surface tests without a trip to memory and for the registers that let the shade phase read a whole
 // row ahead: +1.9 % on the headline frame (42.3 against 43.1 ms per 100 spp).
 constexpr uint32_t WIDE_BLOCK = 1024;
+// First position (of the pixel order) of band `b` of `n`: whole blocks of 32 x 16 pixels, so that the block-by-block order stays intact
+__device__ __forceinline__ uint32_t band_start(uint32_t b, uint32_t n, uint32_t npix) {
+    if (b >= n) return npix;
+    return (uint32_t)(((unsigned long long)npix * b / n) >> 9) << 9;
+}
 template <bool COUNT, bool LDS_NODES, bool BATCH, bool WIDE = false, bool REC16 = false>
 __global__ __launch_bounds__(WIDE ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK, WIDE ? 4 : RTX_PERSISTENT_WAVES) void k_render_persistent(const DRenderParams* P) {
     if (LDS_NODES) stage_scene_in_lds(P);
@@ -1638,6 +1648,11 @@ __global__ __launch_bounds__(WIDE ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK, WIDE ? 4 
     unsigned long long n_rays = 0;
     uint32_t rounds = 0, count = 0, parity = 0;
     bool exhausted = false;
+    // bands of the image with a path counter each (trees walked from global memory: see the top-up below)
+    const uint32_t n_regions = uniform32(P->xcd_bands);
+    const uint32_t npix_all = uniform32(P->cam.image_width) * uniform32(P->cam.image_height);
+    const uint32_t spp_count = n_regions > 1u ? (uint32_t)(total / npix_all) : 0u;
+    uint32_t band = n_regions > 1u ? uniform32(blockIdx.x % n_regions) : 0u, bands_dry = 0u;
 #ifdef RTX_PROFILE_PHASES
     long long pp_gen = 0, pp_trav = 0, pp_shade = 0, pp_mark = clock64();
     const long long pp_begin = pp_mark;
@@ -1648,20 +1663,44 @@ __global__ __launch_bounds__(WIDE ? WIDE_BLOCK : RTX_PERSISTENT_BLOCK, WIDE ? 4 
     for (;;) {
         // top up the sub-pool with the next paths of the call
         if (!exhausted && count < cap) {
-            const uint32_t need = cap - count;
-            unsigned long long first = 0;
-            if (lane == 0) first = atomicAdd(&ctl->next_path[0], (unsigned long long)need);
-            first = uniform64(first);
-            uint32_t got = 0;
-            if (first >= total) {
-                exhausted = true;
+            if (n_regions <= 1u) {
+                const uint32_t need = cap - count;
+                unsigned long long first = 0;
+                if (lane == 0) first = atomicAdd(&ctl->next_path[0], (unsigned long long)need);
+                first = uniform64(first);
+                uint32_t got = 0;
+                if (first >= total) {
+                    exhausted = true;
+                } else {
+                    const unsigned long long rest = total - first;
+                    got = rest < need ? (uint32_t)rest : need;
+                    exhausted = rest <= need;
+                }
+                if (got) phase_generate(P, parity, base + count, first, got, 0u, 0u);
+                count += got;
             } else {
-                const unsigned long long rest = total - first;
-                got = rest < need ? (uint32_t)rest : need;
-                exhausted = rest <= need;
+                // The image is cut into as many bands as there are XCDs and every band has a path counter of its own.  A wave starts
+                // in the band of its block (blocks b and b + 8 run on the same XCD) and moves on to the next band when one runs dry,
+                // so an XCD's L2 mostly sees the part of the tree the rays of one band wander through.
+                while (count < cap && bands_dry < n_regions) {
+                    const uint32_t need = cap - count;
+                    const uint32_t band_base = band_start(band, n_regions, npix_all), band_npix = band_start(band + 1u, n_regions, npix_all) - band_base;
+                    const unsigned long long band_total = (unsigned long long)band_npix * spp_count;
+                    unsigned long long first = band_total;
+                    if (lane == 0 && band_total != 0ull) first = atomicAdd(&ctl->band_next[band], (unsigned long long)need);
+                    first = uniform64(first);
+                    if (first >= band_total) {
+                        ++bands_dry;
+                        band = band + 1u == n_regions ? 0u : band + 1u;
+                        continue;
+                    }
+                    const unsigned long long rest = band_total - first;
+                    const uint32_t got = rest < need ? (uint32_t)rest : need;
+                    phase_generate(P, parity, base + count, first, got, band_base, band_npix);
+                    count += got;
+                }
+                exhausted = bands_dry >= n_regions;
             }
-            if (got) phase_generate(P, parity, base + count, first, got);
-            count += got;
         }
         if (count == 0u) break;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

@@ -126,6 +126,33 @@ def test_quantised_node_records_give_the_reference_answer(rt, oracle, name, batc
         assert np.array_equal(bits(acc.cpu().numpy() + 0.0), bits(want + 0.0))
 
 
+@pytest.mark.parametrize("bands", ["8", "3", "0"])
+def test_image_in_bands_with_a_path_counter_each(rt, oracle, bands, monkeypatch):
+    """Trees walked from global memory take the pixels of large frames block by block and in bands, one per XCD, each band with
+    its own path counter (a wave moves on to the next band when its own runs dry).  Every (pixel, sample) must still be rendered
+    exactly once: a 1280 x 832 frame (2^20 pixels and more; a band boundary inside a row of blocks) at one and at three samples per
+    pixel against the oracle, for eight bands, for a count that does not divide the frame, and for one counter."""
+    import torch
+
+    monkeypatch.setenv("RTX_XCD_BANDS", bands)
+    monkeypatch.setenv("RTX_LDS_WIDE_BYTES", "0")
+    surfaces, cam = S.synthetic_soup(n=30_000, kind="spheres", seed=5, image_width=1280, samples_per_pixel=1)
+    cam = dict(cam, aspect_ratio=1280.0 / 832.0, max_depth=4)
+    dev, orc = rt.Scene(rt.HostBVH(surfaces)), oracle.Scene(surfaces)
+    icam, ocam = rt.camera_initialize(cam), oracle.camera_initialize(cam)
+    assert (icam.image_width, icam.image_height) == (1280, 832)
+    stream = torch.cuda.current_stream().cuda_stream
+    for begin, count in ((0, 1), (5, 3)):
+        acc = torch.zeros(832, 1280, 3, dtype=torch.float64, device="cuda")
+        st = dev.render_accumulate(icam, 11, begin, count, acc.data_ptr(), stream)
+        want, ctr = orc.render(ocam, 11, begin, count, iterative=True)
+        assert st.kernel_form == rt.FORM_POOLED and st.rays == ctr.rays and st.paths == ctr.paths == 1280 * 832 * count
+        if count == 1:
+            assert np.array_equal(bits(acc.cpu().numpy() + 0.0), bits(want + 0.0))
+        else:
+            assert np.allclose(acc.cpu().numpy(), want, rtol=1e-13, atol=0)
+
+
 def test_quantised_records_degenerate_rays(rt, oracle, monkeypatch):
     """Zero, tiny, huge and non-finite direction components and origins far outside the grid."""
     monkeypatch.setenv("RTX_NODE16", "1")

@@ -20,7 +20,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "raytracing_amd", "csrc", "rtx_kernels.hip")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-munsafe-fp-atomics"]
 ROW_LOADS = 15          # loads per row_request
-WALK_LOADS = 6          # the closest-hit walk's own non-temporal loads come first in the kernel
 
 
 def compile_to_asm(path):
@@ -57,6 +56,7 @@ def check(lines, name, a, b):
     # The rows live between the first row's loads and the kernel's last inline-assembly block that loads, waits, adds or stores (row_request, row_wait, row_tail);
     # what follows in the text (the tail phase, the sums of the work counters) may use any register and has loads of its own.
     last_asm, inside, row_block = len(body), False, False
+    in_asm = set()   # lines inside inline-assembly blocks
     for i, l in enumerate(body):   # inline-assembly blocks of row_request / row_wait / row_tail: they load, wait, add or store
         if ";;#ASMSTART" in l:
             inside, row_block = True, False
@@ -64,12 +64,16 @@ def check(lines, name, a, b):
             if inside and row_block:
                 last_asm = i
             inside = False
-        elif inside and re.search(r"global_load_dword|s_waitcnt vmcnt|global_atomic_add_f64|global_store_dword", l):
-            row_block = True
-    nt = [(i, l) for i, l in code if i <= last_asm and re.search(r"global_load_dword(x2)?\s.*off nt", l)]
-    if len(nt) != WALK_LOADS + 2 * ROW_LOADS:
-        return ["%s: %d non-temporal loads, expected %d (has the kernel changed?)" % (name, len(nt), WALK_LOADS + 2 * ROW_LOADS)]
-    first, again = nt[WALK_LOADS:WALK_LOADS + ROW_LOADS], nt[WALK_LOADS + ROW_LOADS:]
+        elif inside:
+            in_asm.add(i)
+            if re.search(r"global_load_dword|s_waitcnt vmcnt|global_atomic_add_f64|global_store_dword", l):
+                row_block = True
+    # the rows' loads are the non-temporal loads issued by inline assembly (the closest-hit walk has non-temporal loads of its
+    # own, emitted by the compiler, wherever the compiler places that code)
+    nt = [(i, l) for i, l in code if i in in_asm and re.search(r"global_load_dword(x2)?\s.*off nt", l)]
+    if len(nt) != 2 * ROW_LOADS:
+        return ["%s: %d non-temporal loads in inline assembly, expected %d (has the kernel changed?)" % (name, len(nt), 2 * ROW_LOADS)]
+    first, again = nt[:ROW_LOADS], nt[ROW_LOADS:]
     dest = set()
     for _, l in again:
         dest |= registers(l.split(",")[0])
