@@ -374,6 +374,10 @@ def main():
     ap.add_argument("--time-kernels", action="store_true", help="round-loop path with per-kernel HIP event timing (diagnostic)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # one bare frame under rocprofv3
     ap.add_argument("--force-spawn", action="store_true", help="start the ranks as child processes even for --gpus 1 (exercises the launcher)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend of the ranks; gloo (through host memory) only to rehearse the N-rank path where RCCL cannot run: not a measurement")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal: rank r uses GPU r modulo the GPUs there are, so N ranks can run on fewer than N GPUs (needs --backend gloo: RCCL refuses two ranks on one GPU)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     # Libraries below (RCCL prints a version banner) may write to stdout; the one JSON line must be all that this process
@@ -398,12 +402,21 @@ def main():
     world = 1 if args.single_process else int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and not args.single_process:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.share_gpu:
+        if args.backend != "gloo":
+            raise SystemExit("--share-gpu needs --backend gloo")
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    through_host = args.backend == "gloo"          # the rehearsal backend moves the buffers through host memory
+    cdev = torch.device("cpu") if through_host else dev   # where the bookkeeping tensors of the collectives live
     ranks_seen = 1
     if "WORLD_SIZE" in os.environ and not args.single_process:   # also a world of one, so that the launcher path is the same at every N
-        dist.init_process_group("nccl", device_id=dev)
-        ranks_seen = collective_ranks(dev)   # also sets the communicator up before anything is timed
+        if through_host:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        ranks_seen = collective_ranks(cdev)   # also sets the communicator up before anything is timed
 
     # host side: scene, BVH (SAH PerSurface, the reference's default), camera
     surfaces, cam = make_scene(args.config, args.width, args.spp)
@@ -444,7 +457,13 @@ def main():
             if world > 1:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                reduce_accum(acc, world)
+                if through_host:
+                    host = acc.cpu()
+                    reduce_accum(host, world)
+                    if rank == 0:
+                        acc.copy_(host)
+                else:
+                    reduce_accum(acc, world)
                 e1.record()
                 reduce_events.append((e0, e1))
             if rank == 0:
@@ -457,7 +476,7 @@ def main():
         torch.cuda.synchronize()
 
     if world > 1:   # the reduce's channels for a buffer of this size, before anything is timed (also with --warmup 0)
-        reduce_accum(acc, world)
+        reduce_accum(acc.cpu() if through_host else acc, world)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -470,13 +489,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    work = torch.tensor([sum(s.rays for s in stats), sum(s.paths for s in stats)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    work = torch.tensor([sum(s.rays for s in stats), sum(s.paths for s in stats)], dtype=torch.float64, device=cdev)
     if world > 1:
         # what each rank did: its share of the samples, the device time of its render call and of the reduce as it saw it
         mine = torch.tensor([float(count), sum(s.ms_total for s in stats) / args.steps,
                              sum(a.elapsed_time(b) for a, b in reduce_events) / max(len(reduce_events), 1), elapsed * 1e3 / args.steps],
-                            dtype=torch.float64, device=dev)
+                            dtype=torch.float64, device=cdev)
         everyone = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(everyone, mine)
         per_rank = {"spp_count": [int(v[0].item()) for v in everyone], "ms_render": [round(v[1].item(), 3) for v in everyone],
@@ -520,7 +539,9 @@ def main():
                 "nominal": nominal,
                 "parallelism": ("single GPU" if n_gpus == 1 else
                                 f"spp split over {n_gpus} GPUs, one RCCL reduce; " + ("one process, one host thread per GPU (rtx_multi_render)" if args.single_process
-                                                                                     else "one process per GPU (torch.distributed, nccl backend)")),
+                                                                                     else "one process per GPU (torch.distributed, nccl backend)")
+                                if not through_host else
+                                f"REHEARSAL, not a measurement: {n_gpus} ranks on {torch.cuda.device_count()} GPU(s), reduce through host memory (gloo)"),
                 "ranks_in_collective": ranks_seen,
                 "rays_per_frame": int(rays_per_step),
                 "paths_per_frame": int(paths_per_step),
@@ -531,6 +552,9 @@ def main():
             out["per_rank"] = per_rank
         if scene is not None and stats:
             out["config"]["kernel"] = rt.FORM_KERNEL.get(stats[-1].kernel_form)
+            # the finished frame on rank 0, as one number: the same at every N up to the order of the f64 additions
+            torch.cuda.synchronize()
+            out["config"]["image_checksum"] = float(image.sum().item())
         if args.pmc_child or scene is None:   # a bare frame for the counter passes / the single-process form: no counting pass
             print(json.dumps(out), file=json_out, flush=True)
         else:

@@ -96,3 +96,36 @@ def test_bench_launch_paths_with_a_world_of_one(how):
     else:
         assert d["image_check"]["rays_equal"] and d["image_check"]["max_rel_diff"] <= 1e-12
         assert d["image_check"]["timed_form"] != d["image_check"]["other_form"]
+
+
+def test_bench_with_two_ranks_rehearsed_on_the_gpus_there_are():
+    """The N > 1 path of `python bench.py --gpus N` end to end on a box with fewer GPUs: two ranks, each a process of its own
+    started and watched by the launcher, share the GPU (`--share-gpu`) and sum their buffers through host memory
+    (`--backend gloo`: RCCL refuses two ranks on one device).  Everything but the collective's backend is what an 8-GPU run
+    does: rendezvous, the split of the samples, the reduce onto rank 0, the per-rank fields, the maximum over ranks.  The
+    frame's ray count must equal the single-rank run's: each (pixel, sample) has its own random stream, so it is the same set
+    of paths only if the two ranks' ranges cover the samples exactly once."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "2", "--warmup", "1", "--spp", "9", "--width", "480", "--no-cpu-baseline", "--no-pmc", "--no-cold-frame", "--no-image-check"]
+    lines = {}
+    for n in (1, 2):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--force-spawn", "--backend", "gloo", "--share-gpu", *common]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(out) == 1, r.stdout
+        lines[n] = json.loads(out[0])
+    one, two = lines[1], lines[2]
+    assert two["n_gpus"] == 2 and two["config"]["ranks_in_collective"] == 2
+    assert two["per_rank"]["spp_count"] == [5, 4]
+    assert all(v > 0 for v in two["per_rank"]["ms_render"]) and len(two["per_rank"]["ms_reduce"]) == 2
+    assert two["config"]["paths_per_frame"] == one["config"]["paths_per_frame"] == 480 * 270 * 9
+    assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
+    assert "REHEARSAL" in two["config"]["parallelism"]
+    a, b = one["config"]["image_checksum"], two["config"]["image_checksum"]
+    assert a > 0 and abs(a - b) <= 1e-11 * a          # the summed image of two ranks is the image of one
