@@ -660,7 +660,9 @@ def roofline(rt, scene, n_nodes, icam, stats, begin, count, acc, stream, args):
                    f"read {rd / 1e9:.1f} GB (FETCH_SIZE x 2) + written {wr / 1e9:.1f} GB")
         else:
             src = note
-    if traffic is None:
+    cfg = CONFIGS[args.config]
+    if traffic is None and args.gpus == 1 and (args.spp, args.width) == (cfg["run_spp"], cfg["width"]):
+        # (the committed figure is of the configuration's own frame on one GPU: it says nothing about another frame or a rank's share)
         live_note = src
         traffic, t_rays, src = committed_traffic(args.config, kernel)
         if live_note and src:
