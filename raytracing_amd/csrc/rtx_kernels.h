@@ -26,6 +26,7 @@ void launch_render_persistent(const DRenderParams* params, const DRenderParams& 
 uint32_t resident_waves_per_cu(const DScene& sc, uint32_t batch);   // 0: the kernel cannot be resident with that scene
 void launch_render_resident(const DRenderParams* params, const DRenderParams& host_params, hipStream_t s);
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s);
+void launch_add(const double* in, uint64_t n, double* out, hipStream_t s);   // out[i] += in[i]
 void launch_quantize(const double* in, uint64_t n, uint8_t* out, hipStream_t s);
 void launch_rays_to_state(const double* org, const double* dir, uint64_t n, const DState& st, hipStream_t s);
 void launch_user_ids(const uint32_t* rec_user_id, uint32_t n_spheres, uint32_t* ids, uint64_t n, hipStream_t s);

@@ -1947,6 +1947,10 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
 __global__ __launch_bounds__(BLOCK) void k_scale(const double* in, uint64_t n, double scale, double* out) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) out[i] = in[i] * scale;
 }
+// out[i] += in[i]: the sum of two accumulation buffers on one device (the rehearsal form of the multi-GPU frame)
+__global__ __launch_bounds__(BLOCK) void k_add(const double* in, uint64_t n, double* out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) out[i] += in[i];
+}
 // linear_to_gamma + ppm_pixel, src/camera.rs:248-266
 __global__ __launch_bounds__(BLOCK) void k_quantize(const double* in, uint64_t n, uint8_t* out) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
@@ -2132,6 +2136,9 @@ void launch_render_resident(const DRenderParams* params, const DRenderParams& ho
 }
 void launch_scale(const double* in, uint64_t n, double scale, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_scale, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, in, n, scale, out);
+}
+void launch_add(const double* in, uint64_t n, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_add, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, in, n, out);
 }
 void launch_quantize(const double* in, uint64_t n, uint8_t* out, hipStream_t s) {
     hipLaunchKernelGGL(k_quantize, dim3(grid_for(n, 2048)), dim3(BLOCK), 0, s, in, n, out);

@@ -76,6 +76,8 @@ struct Rank {
 struct rtx_multi {
     std::vector<Rank> ranks;
     int prior_device = 0;
+    bool rehearsal = false;   // RTX_MULTI_SHARE_GPU=1: more ranks than devices, no communicator (see rtx_multi_create)
+    DevBuf<double> staging;   // rehearsal: a rank's buffer brought to device 0 to be added there
     explicit rtx_multi(size_t n) : ranks(n) {}
 };
 
@@ -98,6 +100,8 @@ void destroy(rtx_multi* m) {
         r.accum.release();
         if (r.scene) rtx_scene_destroy(r.scene);
     }
+    if (!m->ranks.empty()) (void)hipSetDevice(m->ranks[0].device);
+    m->staging.release();
     (void)hipSetDevice(m->prior_device);
     delete m;
 }
@@ -111,12 +115,17 @@ int rtx_multi_create(const rtx_scene_desc* desc, int n_gpus, rtx_multi** out) {
     *out = nullptr;
     const int have = rtx_device_count();
     if (have <= 0) return api_fail(RTX_ERR_NO_DEVICE, "rtx_multi_create: no HIP device");
-    if (n_gpus < 1 || n_gpus > have || n_gpus > RTX_MULTI_MAX_GPUS)
+    // Rehearsal of the N-rank path on fewer than N devices (RTX_MULTI_SHARE_GPU=1; tests only, never a measurement): rank g runs on
+    // device g modulo the devices there are, with its own scene handle, stream and host thread like any rank, and because RCCL
+    // refuses two ranks on one device the sum onto rank 0 is made by plain copies and adds instead of the collective.
+    const bool rehearsal = env_u32("RTX_MULTI_SHARE_GPU", 0, true) != 0u && n_gpus > have;
+    if (n_gpus < 1 || (n_gpus > have && !rehearsal) || n_gpus > RTX_MULTI_MAX_GPUS)
         return api_fail(RTX_ERR_BAD_ARG, "rtx_multi_create: n_gpus = " + std::to_string(n_gpus) + ", " + std::to_string(have) +
                                              " device(s) visible, at most " + std::to_string(RTX_MULTI_MAX_GPUS) + " supported");
     Rccl& nc = rccl();
-    if (!nc.error.empty()) return api_fail(RTX_ERR_RCCL, "rtx_multi_create: " + nc.error);
+    if (!rehearsal && !nc.error.empty()) return api_fail(RTX_ERR_RCCL, "rtx_multi_create: " + nc.error);
     rtx_multi* m = new rtx_multi((size_t)n_gpus);
+    m->rehearsal = rehearsal;
     (void)hipGetDevice(&m->prior_device);
     auto bail = [&](int code) {
         const std::string msg = rtx_last_error();   // the clean-up below must not replace the message
@@ -126,18 +135,20 @@ int rtx_multi_create(const rtx_scene_desc* desc, int n_gpus, rtx_multi** out) {
     std::vector<int> devs((size_t)n_gpus);
     for (int g = 0; g < n_gpus; ++g) {
         Rank& r = m->ranks[(size_t)g];
-        r.device = devs[(size_t)g] = g;
-        if (hipSetDevice(g) != hipSuccess) return bail(api_fail(RTX_ERR_HIP, "rtx_multi_create: hipSetDevice(" + std::to_string(g) + ") failed"));
+        r.device = devs[(size_t)g] = g % have;
+        if (hipSetDevice(r.device) != hipSuccess) return bail(api_fail(RTX_ERR_HIP, "rtx_multi_create: hipSetDevice(" + std::to_string(r.device) + ") failed"));
         int rc = rtx_scene_create(desc, &r.scene);   // the whole scene in every device's HBM
         if (rc != RTX_OK) return bail(rc);
         if (hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess)
             return bail(api_fail(RTX_ERR_HIP, "rtx_multi_create: hipStreamCreate failed"));
     }
     // The communicator clique is set up here, once, and kept: it takes hundreds of milliseconds, more than a frame.
-    std::vector<ncclComm_t> comms((size_t)n_gpus, nullptr);
-    const ncclResult_t e = nc.CommInitAll(comms.data(), n_gpus, devs.data());
-    if (e != ncclSuccess) return bail(api_fail(RTX_ERR_RCCL, std::string("ncclCommInitAll: ") + nc.GetErrorString(e)));
-    for (int g = 0; g < n_gpus; ++g) m->ranks[(size_t)g].comm = comms[(size_t)g];
+    if (!rehearsal) {
+        std::vector<ncclComm_t> comms((size_t)n_gpus, nullptr);
+        const ncclResult_t e = nc.CommInitAll(comms.data(), n_gpus, devs.data());
+        if (e != ncclSuccess) return bail(api_fail(RTX_ERR_RCCL, std::string("ncclCommInitAll: ") + nc.GetErrorString(e)));
+        for (int g = 0; g < n_gpus; ++g) m->ranks[(size_t)g].comm = comms[(size_t)g];
+    }
     (void)hipSetDevice(m->prior_device);
     *out = m;
     return RTX_OK;
@@ -207,16 +218,36 @@ int rtx_multi_render(rtx_multi* m, const rtx_camera* cam, uint64_t seed, uint32_
     // Phase 2, the one collective of the frame: every device's rank of the sum onto device 0, as one group.
     const auto t_reduce = std::chrono::steady_clock::now();
     int comm_ranks = 0;
-    (void)nc.CommCount(m->ranks[0].comm, &comm_ranks);
-    ncclResult_t e = nc.GroupStart();
-    for (uint32_t g = 0; g < world && e == ncclSuccess; ++g) {
-        Rank& r = m->ranks[g];
-        e = nc.Reduce(r.accum.p, r.accum.p, nval, ncclDouble, ncclSum, 0, r.comm, r.stream);
-    }
-    const ncclResult_t e_end = nc.GroupEnd();
-    if (e == ncclSuccess) e = e_end;
-    if (e != ncclSuccess) {
-        return api_fail(RTX_ERR_RCCL, std::string("rtx_multi_render: ncclReduce: ") + nc.GetErrorString(e));
+    if (m->rehearsal) {
+        // no communicator (see rtx_multi_create): every other rank's buffer is brought to device 0 and added there, in rank order
+        Rank& r0 = m->ranks[0];
+        HIP_TRY(hipSetDevice(r0.device));
+        HIP_TRY(m->staging.resize(nval));
+        comm_ranks = 1;
+        for (uint32_t g = 1; g < world; ++g) {
+            Rank& r = m->ranks[g];
+            const double* src = r.accum.p;
+            if (r.device != r0.device) {
+                HIP_TRY(hipMemcpyPeerAsync(m->staging.p, r0.device, r.accum.p, r.device, nval * sizeof(double), r0.stream));
+                src = m->staging.p;
+            }
+            launch_add(src, nval, r0.accum.p, r0.stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(r0.stream));   // (the staging buffer is reused by the next rank)
+            ++comm_ranks;
+        }
+    } else {
+        (void)nc.CommCount(m->ranks[0].comm, &comm_ranks);
+        ncclResult_t e = nc.GroupStart();
+        for (uint32_t g = 0; g < world && e == ncclSuccess; ++g) {
+            Rank& r = m->ranks[g];
+            e = nc.Reduce(r.accum.p, r.accum.p, nval, ncclDouble, ncclSum, 0, r.comm, r.stream);
+        }
+        const ncclResult_t e_end = nc.GroupEnd();
+        if (e == ncclSuccess) e = e_end;
+        if (e != ncclSuccess) {
+            return api_fail(RTX_ERR_RCCL, std::string("rtx_multi_render: ncclReduce: ") + nc.GetErrorString(e));
+        }
     }
     HIP_TRY(hipSetDevice(m->ranks[0].device));
     // `* self.pixel_samples_scale` (src/camera.rs:146) on the summed image

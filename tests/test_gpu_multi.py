@@ -29,6 +29,38 @@ def test_multi_render_on_the_visible_devices_equals_single_device_render(rt):
         multi.close()
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_more_ranks_than_devices_rehearsed_from_one_process(rt, monkeypatch, world):
+    """RTX_MULTI_SHARE_GPU=1: rtx_multi_* with more ranks than there are devices.  Every rank keeps its own scene handle,
+    stream, host thread and share of the samples; the ranks share devices, so the sum onto rank 0 is made with copies and
+    adds instead of the collective (RCCL refuses two ranks on one device).  What it checks is everything but the
+    collective: the sample ranges in C++, concurrent frames on separate handles, the totals, the scaling, the caller's device."""
+    import torch
+
+    if world <= rt.device_count():
+        pytest.skip("this many devices are really there")
+    monkeypatch.setenv("RTX_MULTI_SHARE_GPU", "1")
+    surfaces, cam = S.cover_spheres()
+    cam = dict(cam, image_width=200, samples_per_pixel=11)
+    bvh = rt.HostBVH(surfaces)
+    icam = rt.camera_initialize(cam)
+    want, st = rt.Scene(bvh).render(icam, 23)
+    before = torch.cuda.current_device()
+    multi = rt.MultiScene(bvh, world)
+    for _ in range(2):
+        img, ms = multi.render(icam, 23)
+        assert (ms.n_gpus, ms.collective_ranks) == (world, world)
+        assert (ms.rays, ms.paths) == (st.rays, st.paths)
+        assert list(ms.spp_count[:world]) == [11 // world + (1 if g < 11 % world else 0) for g in range(world)]
+        assert [ms.spp_begin[g] for g in range(world)] == [sum(ms.spp_count[:g]) for g in range(world)]
+        np.testing.assert_allclose(img, want, rtol=1e-13, atol=0)
+    multi.close()
+    assert torch.cuda.current_device() == before
+    monkeypatch.delenv("RTX_MULTI_SHARE_GPU")
+    with pytest.raises(rt.RtxError):
+        rt.MultiScene(bvh, rt.device_count() + 1)   # without the variable the count of devices is the limit, as before
+
+
 def test_one_shot_render_multi_and_errors(rt):
     import ctypes as C
 
