@@ -882,12 +882,19 @@ int rtx_render_accumulate(rtx_scene* sc, const rtx_camera* cam, uint64_t seed, u
             if (pr[7])
                 std::fprintf(stderr, "PHASES per wave (cycles): generate %.0f traverse %.0f shade %.0f, life %.0f (longest %llu), %llu waves\n",
                              (double)pr[0] / pr[7], (double)pr[1] / pr[7], (double)pr[2] / pr[7], (double)pr[6] / pr[7], pr[9], pr[7]);
-            unsigned long long tr[14];
+            unsigned long long tr[16];
             (void)hipMemcpy(tr, reinterpret_cast<unsigned long long*>(pp->ctl.p + 1), sizeof(tr), hipMemcpyDeviceToHost);
             const double all = (double)(tr[0] + tr[1] + tr[2] + tr[3]);
             if (all > 0)
                 std::fprintf(stderr, "PHASES of the walk (share of its cycles): refill %.3f node loop %.3f surface tests %.3f retire %.3f; %.1f node-loop steps per pass of the outer loop\n",
                              tr[0] / all, tr[1] / all, tr[2] / all, tr[3] / all, tr[5] ? (double)tr[4] / tr[5] : 0.0);
+            if (resident && tr[7])   // the resident form's waves: "refill" = new primary rays and ray set-up, "retire" = the bounce
+                std::fprintf(stderr, "PHASES of a resident wave: %.0f cycles, %.1f passes of the walk per bounce, %.0f node-loop steps and %.0f bounces per wave; staging %.3f and taking %.3f of the cycles besides (%.0f stagings per wave)\n",
+                             (double)tr[6] / tr[7], tr[12] ? (double)tr[5] / tr[12] : 0.0, (double)tr[4] / tr[7], (double)tr[12] / tr[7],
+                             tr[13] / (all + tr[13] + tr[14]), tr[14] / (all + tr[13] + tr[14]), (double)tr[15] / tr[7]);
+            if (resident && tr[7] && tr[9])   // (the instrumented build keeps the compiler's form of the node loop)
+                std::fprintf(stderr, "PHASES of a resident wave's node loop: the loop proper %.3f of the cycles (the 'node loop' share above is then what surrounds it), %.0f steps of the wave at %.1f cycles each, %.1f lanes in a step, %.1f steps per pass\n",
+                             tr[8] / (all + tr[8] + tr[13] + tr[14]), (double)tr[9] / tr[7], (double)tr[8] / tr[9], (double)tr[10] / tr[9], tr[5] ? (double)tr[9] / tr[5] : 0.0);
         }
 #endif
         return RTX_OK;

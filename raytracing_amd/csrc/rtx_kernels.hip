@@ -637,7 +637,7 @@ struct WorkCounters {
 // Counters of an instrumented build (-DRTX_PROFILE_PHASES): where a wave's cycles go in the closest-hit walk
 #ifdef RTX_PROFILE_PHASES
 struct WalkProfile {
-    long long fb_iters = 0, fb_cycles = 0, refill = 0, p1 = 0, p2 = 0, retire = 0, iters = 0, outer = 0, mark = 0;
+    long long fb_iters = 0, fb_cycles = 0, refill = 0, p1 = 0, p2 = 0, retire = 0, iters = 0, outer = 0, mark = 0, stage = 0, take = 0, stagings = 0, loop = 0, wave_steps = 0;
 };
 #define PT(field) do { const long long now_ = clock64(); prof.field += now_ - prof.mark; prof.mark = now_; } while (0)
 #else
@@ -645,11 +645,82 @@ struct WalkProfile {};
 #define PT(field) do {} while (0)
 #endif
 
+// The node loop of walk_pass for f32 records in LDS, written out: the loop a wave goes round 25 times per ray.  The compiler's
+// form of it spends 43 instructions on a step: its exit logic keeps three masks (lanes that left, lanes that leave now, the
+// threshold), and it waits for the two reads one by one.  This one spends 35 (24 of them vector instructions instead of 26): both reads, one wait, the box test exactly as
+// box_hit_tier1<false> compiles (the same operations in the same order, hence the same bits), the link select, and an exit
+// that needs one mask; lanes on an undecided box are remembered in a scalar mask.  Worth 1.3 % of the headline frame.  (Measured
+// on this loop, same frame: the margin taken as a constant, wrongly, -1.4 %; four more register moves +1.6 %; one more read of the record per step +0.7 %; the next record requested
+// before the margin and the exit test are evaluated, which takes two more vector instructions, +1.4 %.)
+// A lane's `at` is the LDS address of its record; it ends at `end` or beyond (out of tree), with WAIT (0x80000000, part of a
+// leaf's `down` link as stored) once it stands on a leaf whose box is hit, or with OPEN (0x40000000) on a box the tier cannot
+// decide.  Lanes with at >= end take no part.  The loop ends when no lane walks any more or `pend_at` lanes have started waiting
+// on a leaf.  For kernels built for 128 vector registers: the record and the temporaries sit in v104-v112.
+// Wait states: a vector instruction that reads a mask written by a vector compare comes at least two instructions after it.
+typedef uint32_t u32x4_reg __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void node_loop_lds_f32(uint32_t& at, const RayF32& rf, uint32_t end, uint32_t pend_at) {
+    uint32_t n_pending = 0, cnt, tmp_a;
+    u32x4_reg rec_a, rec_b;   // lo.x hi.x lo.y hi.y | lo.z hi.z miss down
+    unsigned long long saved, mask, undecided, open = 0;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmp_gt_u32_e32 vcc, %[end], %[at]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "s_cbranch_execz .Lrtx_nl_done_%=\n"
+        ".Lrtx_nl_loop_%=:\n\t"
+        "ds_read_b128 v[104:107], %[at]\n\t"
+        "ds_read_b128 v[108:111], %[at] offset:16\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_fma_f32 v104, v104, %[ix], -%[ox]\n\t"
+        "v_fma_f32 v105, v105, %[ix], -%[ox]\n\t"
+        "v_fma_f32 v106, v106, %[iy], -%[oy]\n\t"
+        "v_fma_f32 v107, v107, %[iy], -%[oy]\n\t"
+        "v_fma_f32 v108, v108, %[iz], -%[oz]\n\t"
+        "v_fma_f32 v109, v109, %[iz], -%[oz]\n\t"
+        "v_min_f32_e32 v112, v104, v105\n\t"          // near x
+        "v_max_f32_e32 v104, v104, v105\n\t"          // far x
+        "v_min_f32_e32 v105, v106, v107\n\t"          // near y
+        "v_max_f32_e32 v106, v106, v107\n\t"          // far y
+        "v_min_f32_e32 v107, v108, v109\n\t"          // near z
+        "v_max_f32_e32 v108, v108, v109\n\t"          // far z
+        "v_max_f32_e32 v112, v112, v105\n\t"
+        "v_min_f32_e32 v104, v104, v106\n\t"
+        "v_max3_f32 v112, v112, v107, %[tmin]\n\t"    // lo, clamped
+        "v_min3_f32 v104, v104, v108, %[tmax]\n\t"    // hi, clamped
+        "v_max3_f32 v105, |v112|, |v104|, %[tg]\n\t"  // M
+        "v_sub_f32_e32 v106, v104, v112\n\t"          // m = hi - lo
+        "v_fmamk_f32 v105, v105, 0x35433333, %[K]\n\t"   // T = M * 12.2u + K
+        "v_cmp_gt_f32_e64 %[mk], v106, v105\n\t"      // hit
+        "v_cmp_gt_f32_e64 vcc, |v106|, v105\n\t"      // decided
+        "s_andn2_b64 %[un], exec, vcc\n\t"            // the lanes this step leaves undecided (one visit in 25 000) ...
+        "s_or_b64 %[op], %[op], %[un]\n\t"            // ... are remembered in a mask and leave the loop below
+        "v_cndmask_b32_e64 %[at], v110, v111, %[mk]\n\t"   // hit ? down : miss
+        "v_cmp_gt_i32_e32 vcc, 0, %[at]\n\t"          // starts waiting on a leaf (WAIT is the sign bit)
+        "v_cmp_gt_u32_e64 %[mk], %[end], %[at]\n\t"   // walks on
+        "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+        "s_add_u32 %[np], %[np], %[cnt]\n\t"
+        "s_andn2_b64 exec, %[mk], %[un]\n\t"
+        "s_cbranch_execz .Lrtx_nl_done_%=\n\t"
+        "s_cmp_lt_u32 %[np], %[pend]\n\t"
+        "s_cbranch_scc1 .Lrtx_nl_loop_%=\n"
+        ".Lrtx_nl_done_%=:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [at] "+v"(at), [np] "+s"(n_pending), [op] "+s"(open), [cnt] "=&s"(cnt), [sv] "=&s"(saved), [mk] "=&s"(mask), [un] "=&s"(undecided),
+          "=&{v[104:107]}"(rec_a), "=&{v[108:111]}"(rec_b), "=&{v112}"(tmp_a)
+        : [ix] "v"(rf.inv[0]), [iy] "v"(rf.inv[1]), [iz] "v"(rf.inv[2]), [ox] "v"(rf.oi[0]), [oy] "v"(rf.oi[1]), [oz] "v"(rf.oi[2]), [tmin] "v"(rf.tmin32),
+          [tmax] "v"(rf.tmax32), [tg] "v"(rf.tg), [K] "v"(rf.K), [end] "s"(end), [pend] "s"(pend_at)
+        : "vcc", "scc", "memory");
+    // An undecided lane has left the loop with the wrong link in `at`: its node is the one whose `down` link it read last (an
+    // internal node's is the next record, a leaf's the same with WAIT), and the exact tiers expect it there with OPEN set.
+    if (open != 0ull && ((open >> lane_id()) & 1ull) != 0ull) at = ((rec_b.w & 0x7FFFFFFFu) - 32u) | 0x40000000u;
+}
+
 // One pass of the closest-hit walk over the rays the lanes of a wave hold (`have`: this lane holds one; `node`: the record it
 // stands on, `end` or beyond once it has run out of tree): phase 1 walks nodes until enough lanes stand on a leaf whose box is
 // hit, phase 1b resolves the boxes the f32 tier left undecided, phase 2 tests the surfaces of the waiting lanes.
 // REC16 (trees in global memory only): the 16-byte quantised records (DNode16) instead of the 32-byte f32 ones.
-template <bool COUNT, bool LDS_NODES, bool BATCH, bool REC16>
+// ASM: the node loop as node_loop_lds_f32 (callers built for 128 vector registers; trees in LDS, f32 records, no counting)
+template <bool COUNT, bool LDS_NODES, bool BATCH, bool REC16, bool ASM = false>
 __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& w, bool have, const V3& o, const V3& d, const RayDiv& rdiv, RayF32& rf, double tmin,
                                           double& tmax, uint32_t& best_leaf, uint32_t& node, uint32_t end, uint32_t PEND_AT, bool scene_filter,
                                           uint32_t& c_nodes, uint32_t& c_sph, uint32_t& c_pln, uint32_t& c_fallback, WalkProfile& prof) {
@@ -669,7 +740,14 @@ __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& 
     uint32_t n_pending = 0;   // wave-uniform
     bool undecided = false;
     uint32_t at = have ? node : end;
-    if (at < end) for (;;) {   // lanes leave the loop one by one (test at the bottom); the wave stays until all have left
+#if !defined(RTX_PROFILE_PHASES) && !defined(RTX_NO_ASM_LOOP)
+    constexpr bool asm_loop = ASM && LDS_NODES && !REC16 && !COUNT && !BATCH;
+#else
+    constexpr bool asm_loop = false;
+#endif
+    if (asm_loop) {
+        node_loop_lds_f32(at, rf, end, PEND_AT);
+    } else if (at < end) for (;;) {   // lanes leave the loop one by one (test at the bottom); the wave stays until all have left
         // the record: six planes (f32, or grid steps as f32), whether it is a leaf, its surface code if so,
         // and the byte offset of the record that follows its subtree
         float planes[6];
@@ -723,9 +801,11 @@ __device__ __forceinline__ void walk_pass(const DScene& sc, const TraverseWork& 
         at = decided ? next : (at | OPEN);
 #ifdef RTX_PROFILE_PHASES
         ++prof.iters;
+        if (lane_id() == (uint32_t)__builtin_ctzll(ballot64(true))) ++prof.wave_steps;   // (kept by whichever lane is the first of the step)
 #endif
         if (n_pending >= PEND_AT || at >= end) break;   // the first is wave-uniform
     }
+    PT(loop);
     uint32_t leaf_at = 0;   // f32 records: position of the leaf a waiting lane stands on (its surface code is read below)
     if (have) {
         pending = (at & WAIT) != 0u;
@@ -1768,6 +1848,9 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
     const DRenderParams* P = uniform_ptr(Pin);
     const uint32_t wave = uniform32((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (wave >= uniform32(P->n_sub)) return;
+#ifdef RTX_PROBE_WAVES
+    if ((threadIdx.x >> 6) >= RTX_PROBE_WAVES) return;   // measurement only (-DRTX_PROBE_WAVES=4 / 8 / 12): the frame's time with one, two or three waves per SIMD
+#endif
     const uint32_t lane = lane_id();
     const DScene sc = uniform_scene(P->sc);
     DRenderCtl* const ctl = uniform_p(P->ctl);
@@ -1812,6 +1895,10 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
     uint32_t events = 0;
     uint32_t c_nodes = 0, c_sph = 0, c_pln = 0, c_fallback = 0;
     WalkProfile prof;
+#ifdef RTX_PROFILE_PHASES
+    prof.mark = clock64();
+    const long long pt_begin = prof.mark;
+#endif
 #ifdef RTX_PROBE_NO_ATOMICS
     V3 probe_sum = v3(0, 0, 0);
 #endif
@@ -1850,6 +1937,7 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
                     have = false;
                 }
             }
+            PT(retire);   // (instrumented build: the bounce)
             // ---- the next paths of the call for the lanes without one
             // Primary rays are made 64 at a time (fewer where LDS is short), by the whole wave, and staged in LDS; a lane whose path has ended takes the next
             // staged one (four LDS reads).  Made on demand they cost their ~400 instructions (path index, sample_square, the defocus
@@ -1899,6 +1987,10 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
                         }
                         st_head = 0u;
                         st_cnt = got;
+#ifdef RTX_PROFILE_PHASES
+                        ++prof.stagings;
+#endif
+                        PT(stage);
                     }
                     const uint32_t avail = st_cnt - st_head;
                     const uint32_t take = need < avail ? need : avail;
@@ -1919,6 +2011,7 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
                     need = (uint32_t)__popcll(vacant);
                 }
                 exhausted = drained && chunk_next == chunk_end && st_head == st_cnt;
+                PT(take);
             }
             if (fresh) {
                 tmax = tmax0;
@@ -1929,9 +2022,39 @@ __global__ __launch_bounds__(WIDE_BLOCK, 4) void k_render_resident(const DRender
             }
             n_rays += (unsigned long long)__popcll(ballot64(fresh));
         }
-        walk_pass<false, true, BATCH, false>(sc, w, have, o, d, rdiv, rf, tmin, tmax, best_leaf, node, end, PEND_AT, scene_filter, c_nodes, c_sph, c_pln,
-                                             c_fallback, prof);
+        PT(refill);   // (instrumented build: the set-up of the lanes' new rays and the head of the loop)
+#ifdef RTX_PROFILE_PHASES
+        ++prof.outer;
+#endif
+        walk_pass<false, true, BATCH, false, true>(sc, w, have, o, d, rdiv, rf, tmin, tmax, best_leaf, node, end, PEND_AT, scene_filter, c_nodes, c_sph, c_pln,
+                                                   c_fallback, prof);
     }
+#ifdef RTX_PROFILE_PHASES
+    if (lane == 0) {   // (per-lane counts below are lane 0's: a lane's share of the wave's work)
+        unsigned long long* pr = reinterpret_cast<unsigned long long*>(ctl + 1);   // debug area behind the control block
+        atomicAdd(pr + 0, (unsigned long long)prof.refill);
+        atomicAdd(pr + 1, (unsigned long long)prof.p1);
+        atomicAdd(pr + 2, (unsigned long long)prof.p2);
+        atomicAdd(pr + 3, (unsigned long long)prof.retire);
+        atomicAdd(pr + 4, (unsigned long long)prof.iters);
+        atomicAdd(pr + 5, (unsigned long long)prof.outer);
+        atomicAdd(pr + 6, (unsigned long long)(clock64() - pt_begin));
+        atomicAdd(pr + 7, 1ull);
+        atomicAdd(pr + 12, (unsigned long long)events);
+        atomicAdd(pr + 13, (unsigned long long)prof.stage);
+        atomicAdd(pr + 14, (unsigned long long)prof.take);
+        atomicAdd(pr + 15, (unsigned long long)prof.stagings);
+    }
+    {   // counts kept by whichever lane was the first active one of a step
+        unsigned long long* pr = reinterpret_cast<unsigned long long*>(ctl + 1);
+        const unsigned long long ws = wave_sum((unsigned long long)prof.wave_steps), ls = wave_sum((unsigned long long)prof.iters);
+        if (lane == 0) {
+            atomicAdd(pr + 8, (unsigned long long)prof.loop);
+            atomicAdd(pr + 9, ws);
+            atomicAdd(pr + 10, ls);
+        }
+    }
+#endif
 #ifdef RTX_PROBE_NO_ATOMICS
     unsafeAtomicAdd(accum + 3 * (size_t)lane + 0, probe_sum.x);
     unsafeAtomicAdd(accum + 3 * (size_t)lane + 1, probe_sum.y);
