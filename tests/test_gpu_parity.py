@@ -375,6 +375,32 @@ def test_paths_resident_in_registers_render_the_same_image(rt, oracle, form, mon
     assert np.array_equal(bits(got + 0.0), bits(want + 0.0))
 
 
+@pytest.mark.parametrize("form", ["resident", "pooled"])
+def test_render_far_from_the_origin_where_the_first_tier_often_cannot_decide(rt, oracle, form, monkeypatch):
+    """A field of small spheres 3e5 away from the origin: single-precision box planes are then uncertain by hundredths of a
+    unit, many box tests are left to the exact tiers (counted), and a lane that stood on such a box has to come back to it.
+    Both forms of the single launch give the oracle's samples bit for bit and trace the oracle's number of rays."""
+    import torch
+
+    shift = np.array([3.0e5, -2.0e5, 2.5e5])
+    soup, cam = S.synthetic_soup(n=700, kind="spheres", seed=19, image_width=160, samples_per_pixel=1)
+    soup = soup.copy()
+    soup["q"] = soup["q"] * 0.08 + shift          # 700 spheres of radius 0.05 .. 0.3 in a cube of side 8
+    cam = dict(cam, look_from=tuple(shift + np.array([0.0, 0.0, -14.0])), look_at=tuple(shift), max_depth=8)
+    monkeypatch.setenv("RTX_RESIDENT", "1" if form == "resident" else "0")
+    for seed, sample in ((4, 0), (99, 7)):
+        got, st, want, ctr = render_pair(rt, oracle, soup, cam, seed, sample, 1, iterative=True)
+        assert st.rays == ctr.rays and st.paths == ctr.paths and st.rays > 1.2 * st.paths
+        assert st.kernel_form == (rt.FORM_RESIDENT if form == "resident" else rt.FORM_POOLED)
+        assert np.array_equal(bits(got + 0.0), bits(want + 0.0)), f"{np.count_nonzero(got != want)} values differ"
+    # the scene does what it is for: a good share of the walk's box tests go to the exact tiers
+    dev = rt.Scene(rt.HostBVH(soup))
+    icam = rt.camera_initialize(cam)
+    acc = torch.zeros(icam.image_height, icam.image_width, 3, dtype=torch.float64, device="cuda")
+    counted = dev.render_accumulate(icam, 4, 0, 1, acc.data_ptr(), torch.cuda.current_stream().cuda_stream, rt.FLAG_COUNT_ACTUAL)
+    assert counted.box_fallbacks > 0.02 * counted.node_visits
+
+
 def test_first_call_of_a_scene_measures_its_rays_per_path_with_its_first_sample(rt, oracle, monkeypatch):
     """A scene's first render call of eight samples or more runs its first sample as a launch of its own (which tells how many
     rays a path of the scene traces) and the others in the form that suits: the image and the ray count are those of the oracle
