@@ -302,6 +302,21 @@ def test_single_sample_radiance_bit_exact(rt, oracle, name):
         assert np.array_equal(bits(got + 0.0), bits(want + 0.0)), f"{np.count_nonzero(got != want)} values differ"
 
 
+@pytest.mark.parametrize("name", EXAMPLES)
+def test_single_sample_radiance_bit_exact_with_the_paths_in_registers(rt, oracle, name, monkeypatch):
+    """The same comparison with the resident form of the single launch forced on every example scene (a tree of one node,
+    scenes of quads whose undecided box tests are batched, small sphere scenes): both instances of that kernel, and its
+    node loop, against the oracle bit for bit."""
+    monkeypatch.setenv("RTX_RESIDENT", "1")
+    surfaces, cam = S.EXAMPLES[name]()
+    cam = dict(cam, image_width=min(cam["image_width"], 240))
+    for seed, sample in ((7, 0), (0xBEEF, 13)):
+        got, st, want, ctr = render_pair(rt, oracle, surfaces, cam, seed, sample, 1, iterative=True)
+        assert st.kernel_form == rt.FORM_RESIDENT
+        assert st.rays == ctr.rays and st.paths == ctr.paths
+        assert np.array_equal(bits(got + 0.0), bits(want + 0.0)), f"{np.count_nonzero(got != want)} values differ"
+
+
 @pytest.mark.parametrize("path", ["single_launch", "round_loop"])
 @pytest.mark.parametrize("name", ["cover_spheres", "cornell_box", "demo_spheres"])
 def test_render_work_counters_match_oracle(rt, oracle, name, path, monkeypatch):
