@@ -1253,6 +1253,36 @@ __device__ __forceinline__ void row_tail(unsigned long long add_x, unsigned long
         : "memory");
 }
 
+// Square roots and reciprocals of a bounce, for the lanes that are here: the bare sequences of rtx_device.h (the library's own
+// operations without the scaffolding for operands of extreme magnitude: a third of the instructions) where every lane's
+// operand is between 2^-500 and 2^500, the library forms for all lanes otherwise.  The same roundings either way.
+__device__ __forceinline__ bool in_bare_range(double x) {   // 2^-500 <= x < 2^500; zero, negative numbers, infinities and NaNs are not
+    return (uint32_t)__double2hiint(x) - (523u << 20) < (1000u << 20);
+}
+__device__ __forceinline__ double sqrt_here(double x) {
+    if (__builtin_amdgcn_ballot_w64(!in_bare_range(x)) == 0ull) return sqrt_normal_range(x);
+    return sqrt(x);
+}
+// v / sqrt(v.v) = v * (1.0 / sqrt(v.v)): Vector3::to_unit and the end of Vector3::random_unit (src/vector.rs:39-41, :59-81, :179-190).
+// The root of an operand in range lies between 2^-250 and 2^250, where div_refined's bounds hold with room to spare.
+__device__ __forceinline__ V3 to_unit_here(V3 v) {
+    const double l = length_squared(v);
+    double inv;
+    if (__builtin_amdgcn_ballot_w64(!in_bare_range(l)) == 0ull) {
+        const double root = sqrt_normal_range(l);
+        inv = div_refined(1.0, root, refined_rcp(root));
+    } else {
+        inv = 1.0 / sqrt(l);
+    }
+    return v * inv;
+}
+__device__ __forceinline__ V3 refract_here(V3 r_in, V3 n, double eta) {   // refract of rtx_device.h (src/vector.rs:258-264) with sqrt_here
+    const double cos_theta = clampd(dot(-r_in, n), -1.0, 1.0);
+    const V3 r_out_perp = eta * (r_in + cos_theta * n);
+    const V3 r_out_par = -sqrt_here(fabs(1.0 - length_squared(r_out_perp))) * n;
+    return r_out_perp + r_out_par;
+}
+
 // What one bounce does to the rays a wave holds (`active`: this lane holds one): emitted light and the sky for the rays that
 // end here (`add`, `radiance`: to be added to the ray's pixel) and Material::scatter for the others (`alive`: the path goes on
 // from `p` along `nd` with `beta`, `draw` and `depth`).  Must be called by all 64 lanes: Vector3::random_unit is run for the wave.
@@ -1351,7 +1381,7 @@ __device__ __forceinline__ Bounce bounce_wave(const DScene& sc, const uint4* lds
             V3 unit = v3(0.0, 0.0, 0.0);
             if (mkind <= 2u) {
                 const V3 v = mkind == 2u ? d : ru_cand;
-                unit = v / sqrt(length_squared(v));
+                unit = to_unit_here(v);
             }
             if (mkind <= 1u) {
                 const V3 ru = unit;
@@ -1365,7 +1395,7 @@ __device__ __forceinline__ Bounce bounce_wave(const DScene& sc, const uint4* lds
                 } else {                   // metal, material.rs:84-96
                     V3 reflected = reflect(d, n);
                     V3 fuzz = ru * param;
-                    V3 fuzzed = to_unit(reflected) + fuzz;
+                    V3 fuzzed = to_unit_here(reflected) + fuzz;
                     nd = fuzzed;
                     scattered = dot(fuzzed, n) > 0.0;
                 }
@@ -1373,13 +1403,13 @@ __device__ __forceinline__ Bounce bounce_wave(const DScene& sc, const uint4* lds
                 V3 r_in = unit;
                 double eta = front_face ? rgb.x : param;        // 1.0 / ri : ri
                 double cos_theta = clampd(dot(-r_in, n), -1.0, 1.0);
-                double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+                double sin_theta = sqrt_here(1.0 - cos_theta * cos_theta);
                 bool refl = eta * sin_theta > 1.0;
                 if (!refl) {   // no draw on total internal reflection
                     refl = reflectance(cos_theta, front_face ? rgb.y : rgb.z) > first_uniform_of_block(k0, k1, pixel, sample, draw_ev >> 1);
                     ++draw_ev;
                 }
-                nd = refl ? reflect(r_in, n) : refract(r_in, n, eta);
+                nd = refl ? reflect(r_in, n) : refract_here(r_in, n, eta);
                 scattered = true;
             }
             depth = depth0 + 1u;

@@ -113,6 +113,12 @@ def test_bare_division_and_sqrt_of_the_sphere_test_are_correctly_rounded(rt):
     d[:6] = [1.0, 2.0, 4.0, 2.0 ** -500, 2.0 ** 500, 0.25]
     d = np.clip(d, 2.0 ** -500, 2.0 ** 500)
     assert np.array_equal(bits(rt.selftest_math(6, d, d)), bits(np.sqrt(d)))
+    # the reciprocal of a root (Vector3::to_unit in a bounce: 1.0 / sqrt(v.v) with the root between 2^-250 and 2^250), and either sign
+    root = np.sqrt(d)
+    assert np.array_equal(bits(rt.selftest_math(5, np.ones(n), root)), bits(1.0 / root))
+    sx = x * rng.choice([-1.0, 1.0], n)
+    got = rt.selftest_math(5, num, sx)
+    assert np.array_equal(bits(got)[keep], bits(num / sx)[keep])
 
 
 def test_filtered_quotient_error_bound(rt):
