@@ -978,7 +978,7 @@ __device__ __forceinline__ void traverse_f32_wave(const DScene& sc, const DState
     if (lane == 0 && ctl && p_end > 0) {
         unsigned long long* pr = reinterpret_cast<unsigned long long*>(ctl + 1);   // debug area behind the control block
         atomicAdd(pr + 0, (unsigned long long)prof.refill);
-        atomicAdd(pr + 1, (unsigned long long)prof.p1);
+        atomicAdd(pr + 1, (unsigned long long)(prof.p1 + prof.loop));   // (the loop proper and what surrounds it)
         atomicAdd(pr + 2, (unsigned long long)prof.p2);
         atomicAdd(pr + 3, (unsigned long long)prof.retire);
         atomicAdd(pr + 4, (unsigned long long)prof.iters);
