@@ -161,3 +161,38 @@ def test_bench_with_two_ranks_rehearsed_on_the_gpus_there_are():
     assert "REHEARSAL" in two["config"]["parallelism"]
     a, b = one["config"]["image_checksum"], two["config"]["image_checksum"]
     assert a > 0 and abs(a - b) <= 1e-11 * a          # the summed image of two ranks is the image of one
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("n, extra", [(1, []), (2, ["--backend", "gloo", "--share-gpu"])])
+def test_bench_under_the_launcher_the_scaling_run_uses(n, extra):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
+    --steps K --warmup W`: the command an N-GPU scaling run is started with.  Under it bench.py is one of the ranks (it starts no
+    ranks of its own), rank 0 prints the one JSON line and the others print nothing.  With one rank over RCCL, and with two ranks
+    that share the GPU and sum through host memory (what a one-GPU box can run of N = 2)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+           "--spp", "9", "--width", "480", "--no-cpu-baseline", "--no-pmc", "--no-cold-frame", "--no-image-check", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1
+    assert d["config"]["ranks_in_collective"] == n
+    assert d["config"]["paths_per_frame"] == 480 * 270 * 9 and d["value"] > 0
+    if n == 2:
+        assert d["per_rank"]["spp_count"] == [5, 4] and "REHEARSAL" in d["config"]["parallelism"]
